@@ -1,0 +1,194 @@
+"""Deterministic synthetic weights for the AA-CLIP hot path.
+
+There are no pretrained checkpoints in the container or on the GPU box, so every
+test, the smoke run and bench.py use weights regenerated from a seed.  Each
+tensor gets its own torch CPU generator seeded from crc32(name) ^ seed, so the
+same name always yields the same values on every machine running this image,
+independent of the order tensors are created in.
+
+The standard deviations follow the reference initialisers so activations have
+realistic magnitudes (reference model/transformer.py:606-623: attn D^-1/2,
+proj (2*layers)^-1/2 * D^-1/2, fc (2D)^-1/2; adapters xavier-uniform,
+reference model/adapter.py:107-113).  LayerNorm gains/biases and linear biases
+are made non-trivial on purpose so those code paths are exercised, and the
+q/k rows of in_proj are scaled x2 so softmax rows are not near-uniform.
+
+The key names and shapes are the reference's state-dict contract
+(reference model/model.py:311-369, strict load at model/clip.py:132).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import torch
+
+
+@dataclass
+class TowerCfg:
+    width: int
+    layers: int
+    heads: int
+    mlp: int
+
+
+@dataclass
+class ClipCfg:
+    """Architecture numbers of reference model/model_configs/ViT-L-14-336.json
+    (image_size overridden to 518 by create_model, model/clip.py:112)."""
+    embed_dim: int = 768
+    image_size: int = 518
+    patch_size: int = 14
+    vision: TowerCfg = field(default_factory=lambda: TowerCfg(1024, 24, 16, 4096))
+    text: TowerCfg = field(default_factory=lambda: TowerCfg(768, 12, 12, 3072))
+    context_length: int = 77
+    vocab_size: int = 49408
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+
+def tiny_cfg() -> ClipCfg:
+    """Reduced architecture for fast tests: same structure, head dim 64."""
+    return ClipCfg(
+        embed_dim=128,
+        image_size=70,
+        patch_size=14,
+        vision=TowerCfg(256, 3, 4, 1024),
+        text=TowerCfg(128, 2, 2, 512),
+        context_length=77,
+        vocab_size=49408,
+    )
+
+
+def _gen(name: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def randn(name: str, shape, std: float, seed: int, mean: float = 0.0) -> torch.Tensor:
+    t = torch.randn(*shape, generator=_gen(name, seed), dtype=torch.float32)
+    return t.mul_(std).add_(mean)
+
+
+def uniform(name: str, shape, bound: float, seed: int) -> torch.Tensor:
+    t = torch.rand(*shape, generator=_gen(name, seed), dtype=torch.float32)
+    return t.mul_(2 * bound).sub_(bound)
+
+
+def _tower(sd: Dict[str, torch.Tensor], prefix: str, cfg: TowerCfg, seed: int) -> None:
+    d = cfg.width
+    attn_std = d ** -0.5
+    proj_std = (d ** -0.5) * ((2 * cfg.layers) ** -0.5)
+    fc_std = (2 * d) ** -0.5
+    for i in range(cfg.layers):
+        p = f"{prefix}resblocks.{i}."
+        sd[p + "ln_1.weight"] = randn(p + "ln_1.weight", (d,), 0.1, seed, 1.0)
+        sd[p + "ln_1.bias"] = randn(p + "ln_1.bias", (d,), 0.05, seed)
+        w = randn(p + "attn.in_proj_weight", (3 * d, d), attn_std, seed)
+        w[: 2 * d].mul_(2.0)
+        sd[p + "attn.in_proj_weight"] = w
+        sd[p + "attn.in_proj_bias"] = randn(p + "attn.in_proj_bias", (3 * d,), 0.02, seed)
+        sd[p + "attn.out_proj.weight"] = randn(p + "attn.out_proj.weight", (d, d), proj_std, seed)
+        sd[p + "attn.out_proj.bias"] = randn(p + "attn.out_proj.bias", (d,), 0.02, seed)
+        sd[p + "ln_2.weight"] = randn(p + "ln_2.weight", (d,), 0.1, seed, 1.0)
+        sd[p + "ln_2.bias"] = randn(p + "ln_2.bias", (d,), 0.05, seed)
+        sd[p + "mlp.c_fc.weight"] = randn(p + "mlp.c_fc.weight", (cfg.mlp, d), fc_std, seed)
+        sd[p + "mlp.c_fc.bias"] = randn(p + "mlp.c_fc.bias", (cfg.mlp,), 0.02, seed)
+        sd[p + "mlp.c_proj.weight"] = randn(p + "mlp.c_proj.weight", (d, cfg.mlp), proj_std, seed)
+        sd[p + "mlp.c_proj.bias"] = randn(p + "mlp.c_proj.bias", (d,), 0.02, seed)
+
+
+def synth_clip_state_dict(cfg: ClipCfg, seed: int = 111) -> Dict[str, torch.Tensor]:
+    """Full CLIP state dict with the reference's key names (positional
+    embedding already at the run-time grid, i.e. after resize_pos_embed)."""
+    sd: Dict[str, torch.Tensor] = {}
+    dv, dt = cfg.vision.width, cfg.text.width
+    ps = cfg.patch_size
+    sd["visual.conv1.weight"] = randn("visual.conv1.weight", (dv, 3, ps, ps), (3 * ps * ps) ** -0.5, seed)
+    sd["visual.class_embedding"] = randn("visual.class_embedding", (dv,), dv ** -0.5, seed)
+    sd["visual.positional_embedding"] = randn("visual.positional_embedding", (cfg.tokens, dv), dv ** -0.5, seed)
+    sd["visual.ln_pre.weight"] = randn("visual.ln_pre.weight", (dv,), 0.1, seed, 1.0)
+    sd["visual.ln_pre.bias"] = randn("visual.ln_pre.bias", (dv,), 0.05, seed)
+    _tower(sd, "visual.transformer.", cfg.vision, seed)
+    sd["visual.ln_post.weight"] = randn("visual.ln_post.weight", (dv,), 0.1, seed, 1.0)
+    sd["visual.ln_post.bias"] = randn("visual.ln_post.bias", (dv,), 0.05, seed)
+    sd["visual.proj"] = randn("visual.proj", (dv, cfg.embed_dim), dv ** -0.5, seed)
+    sd["token_embedding.weight"] = randn("token_embedding.weight", (cfg.vocab_size, dt), 0.02, seed)
+    sd["positional_embedding"] = randn("positional_embedding", (cfg.context_length, dt), 0.01, seed)
+    _tower(sd, "transformer.", cfg.text, seed)
+    sd["ln_final.weight"] = randn("ln_final.weight", (dt,), 0.1, seed, 1.0)
+    sd["ln_final.bias"] = randn("ln_final.bias", (dt,), 0.05, seed)
+    sd["text_projection"] = randn("text_projection", (dt, cfg.embed_dim), dt ** -0.5, seed)
+    sd["logit_scale"] = torch.tensor(math.log(1 / 0.07), dtype=torch.float32)
+    return sd
+
+
+def _xavier(name: str, out_f: int, in_f: int, seed: int) -> torch.Tensor:
+    return uniform(name, (out_f, in_f), math.sqrt(6.0 / (in_f + out_f)), seed)
+
+
+def synth_image_adapter_state_dict(cfg: ClipCfg, until: int = 6, levels: int = 4,
+                                   relu: bool = False, seed: int = 111) -> Dict[str, torch.Tensor]:
+    """Keys of AdaptedCLIP.image_adapter (reference model/adapter.py:35-48)."""
+    dv, e = cfg.vision.width, cfg.embed_dim
+    proj_key = "fc.0.weight" if relu else "fc.weight"
+    sd = {}
+    for i in range(until):
+        k = f"layer_adapters.{i}.fc.0.weight"
+        sd[k] = _xavier("image_adapter." + k, dv, dv, seed)
+    for i in range(levels):
+        k = f"seg_proj.{i}.{proj_key}"
+        sd[k] = _xavier("image_adapter." + k, e, dv, seed)
+    k = f"det_proj.{proj_key}"
+    sd[k] = _xavier("image_adapter." + k, e, dv, seed)
+    return sd
+
+
+def synth_text_adapter_state_dict(cfg: ClipCfg, until: int = 3, seed: int = 111) -> Dict[str, torch.Tensor]:
+    """Keys of AdaptedCLIP.text_adapter (reference model/adapter.py:51-54):
+    `until` SimpleAdapter(width,width) then one SimpleProj(width, embed, relu=True)."""
+    dt, e = cfg.text.width, cfg.embed_dim
+    sd = {}
+    for i in range(until):
+        k = f"{i}.fc.0.weight"
+        sd[k] = _xavier("text_adapter." + k, dt, dt, seed)
+    k = f"{until}.fc.0.weight"
+    sd[k] = _xavier("text_adapter." + k, e, dt, seed)
+    return sd
+
+
+def synth_images(batch: int, size: int, seed: int = 111, offset: int = 0) -> torch.Tensor:
+    """CLIP-normalised pixels are ~N(0,1); image i only depends on
+    (seed, offset+i) so any rank can regenerate its shard."""
+    out = torch.empty(batch, 3, size, size, dtype=torch.float32)
+    for i in range(batch):
+        out[i] = torch.randn(3, size, size, generator=_gen(f"image.{offset + i}", seed))
+    return out
+
+
+def synth_masks(batch: int, size: int, seed: int = 111, offset: int = 0) -> torch.Tensor:
+    """Synthetic binary ground-truth masks (random rectangles/ellipses, ~5 %
+    positive) for AUROC parity when no dataset is present."""
+    out = torch.zeros(batch, size, size, dtype=torch.uint8)
+    ys = torch.arange(size).view(-1, 1).float()
+    xs = torch.arange(size).view(1, -1).float()
+    for i in range(batch):
+        g = _gen(f"mask.{offset + i}", seed)
+        r = torch.rand(6, generator=g)
+        cy, cx = (0.15 + 0.7 * r[0]) * size, (0.15 + 0.7 * r[1]) * size
+        hh, hw = (0.05 + 0.12 * r[2]) * size, (0.05 + 0.12 * r[3]) * size
+        if r[4] < 0.5:
+            m = ((ys - cy).abs() <= hh) & ((xs - cx).abs() <= hw)
+        else:
+            m = ((ys - cy) / hh) ** 2 + ((xs - cx) / hw) ** 2 <= 1.0
+        out[i] = m.to(torch.uint8)
+    return out

@@ -1,0 +1,125 @@
+"""Pin the CPU oracle to golden vectors produced by running the reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from aaclip_hip import synth
+from oracle import aaclip_oracle as O
+
+T = torch.from_numpy
+
+
+def close(a, b, atol=2e-5, rtol=2e-4):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst excess {(err - tol).max().item():.3e}"
+
+
+def sampled(golden, name, t, atol=2e-5, rtol=2e-4):
+    assert tuple(golden[f"{name}.shape"]) == tuple(t.shape)
+    f = t.reshape(-1)
+    close(f[T(golden[f"{name}.idx"])], golden[f"{name}.val"], atol, rtol)
+    s = golden[f"{name}.abssum"]
+    assert abs(f.double().abs().sum().item() - s) <= 1e-4 * s
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = synth.tiny_cfg()
+    return cfg, synth.synth_clip_state_dict(cfg, seed=7), synth.synth_images(3, cfg.image_size, seed=7)
+
+
+def test_tiny_encode_image(golden_tiny, tiny):
+    cfg, sd, img = tiny
+    pooled, taps = O.encode_image(img, sd, cfg.vision.heads, [1, 3])
+    close(pooled, golden_tiny["tiny.pooled"])
+    close(taps[0], golden_tiny["tiny.tap1"])
+    close(taps[1], golden_tiny["tiny.tap3"])
+
+
+def test_tiny_encode_text(golden_tiny, tiny):
+    cfg, sd, _ = tiny
+    tok = T(golden_tiny["tiny.tokens"])
+    close(O.encode_text(tok, sd, cfg.text.heads), golden_tiny["tiny.text"])
+
+
+def test_tiny_adapted_stream(golden_tiny, tiny):
+    cfg, sd, img = tiny
+    ia = synth.synth_image_adapter_state_dict(cfg, until=2, levels=2, seed=7)
+    _, _, stream = O.adapted_visual_forward(img, sd, ia, cfg.vision.heads, image_adapt_until=2,
+                                            levels=(2, 3), return_stream=True)
+    close(stream[-1], golden_tiny["tiny.adapted_stream"])
+
+
+def test_resize_pos_embed(golden_tiny):
+    close(O.resize_pos_embed(T(golden_tiny["resize.in"]), 37), golden_tiny["resize.out"], atol=1e-6)
+
+
+def test_similarity_map_pieces(golden_tiny):
+    pf, tf = T(golden_tiny["map.pf"]), T(golden_tiny["map.tf"])
+    close(O.similarity_map(pf, tf, 70, test=False), golden_tiny["map.train"], atol=1e-5)
+    s = 100.0 * torch.matmul(pf, tf)
+    pre = ((s[..., 1] + 1 - s[..., 0]) / 2).view(2, 1, 5, 5)
+    close(pre, golden_tiny["map.pre_blur"], atol=1e-5)
+    close(O.bilinear_align_corners(pre, 70), golden_tiny["map.pre_blur_up"], atol=1e-5)
+
+
+def test_blur_properties():
+    # parity unpinned (kornia absent): check the restated algorithm's invariants
+    x = torch.ones(1, 1, 9, 9)
+    assert torch.allclose(O.gaussian_blur2d(x, 7, 1.0), x, atol=1e-6)
+    k = O.gaussian_kernel1d(7, 1.0, torch.float64)
+    assert abs(k.sum().item() - 1) < 1e-12 and torch.allclose(k, k.flip(0))
+    ref = torch.exp(-torch.arange(-3, 4, dtype=torch.float64) ** 2 / 2)
+    assert torch.allclose(k, ref / ref.sum())
+    d = torch.zeros(1, 1, 11, 11)
+    d[0, 0, 5, 5] = 1
+    b = O.gaussian_blur2d(d, 7, 1.0)
+    assert torch.allclose(b[0, 0, 2:9, 2:9], torch.outer(k, k).float(), atol=1e-7)
+
+
+@pytest.fixture(scope="module")
+def full():
+    cfg = synth.ClipCfg()
+    return (cfg, synth.synth_clip_state_dict(cfg, seed=111), synth.synth_image_adapter_state_dict(cfg, seed=111),
+            synth.synth_text_adapter_state_dict(cfg, seed=111))
+
+
+def test_full_adapted_visual(golden_full, full):
+    cfg, sd, ia, _ = full
+    torch.set_num_threads(8)
+    img = synth.synth_images(2, 518, seed=111)
+    seg, det, stream = O.adapted_visual_forward(img, sd, ia, cfg.vision.heads, return_stream=True)
+    for i in range(4):
+        sampled(golden_full, f"full.seg{i}", seg[i], atol=2e-5, rtol=1e-3)
+        sampled(golden_full, f"full.stream{i}", stream[i][:, 1:], atol=2e-4, rtol=1e-3)
+    close(det, golden_full["full.det"], atol=1e-5, rtol=1e-3)
+    # map pieces and the reference's image-score quirk on the golden anchors
+    anchors = T(golden_full["full.anchors_bottle"])
+    tfb = anchors.unsqueeze(0).repeat(2, 1, 1)
+    for i in range(4):
+        s = 100.0 * torch.matmul(seg[i], tfb)
+        pre = ((s[..., 1] + 1 - s[..., 0]) / 2).view(2, 37, 37)
+        close(pre, golden_full[f"full.map_pre_blur{i}"], atol=2e-3, rtol=1e-3)
+    sampled(golden_full, "full.map_train3", O.similarity_map(seg[3], tfb, 518, test=False), atol=1e-4, rtol=1e-3)
+    close(O.image_score_reference_quirk(det, tfb), golden_full["full.image_pred_quirk"], atol=1e-5)
+
+
+def test_full_text(golden_full, full):
+    cfg, sd, _, ta = full
+    tok = T(golden_full["full.text_tokens"])
+    close(O.adapted_encode_text(tok, sd, ta, cfg.text.heads), golden_full["full.text_adapted"], atol=2e-5, rtol=1e-3)
+    close(O.encode_text(tok, sd, cfg.text.heads), golden_full["full.text_plain"], atol=2e-5, rtol=1e-3)
+
+
+def test_full_encode_image(golden_full, full):
+    cfg, sd, _, _ = full
+    img = synth.synth_images(1, 518, seed=111)
+    pooled, taps = O.encode_image(img, sd, cfg.vision.heads, [6, 24])
+    close(pooled, golden_full["full.pooled"], atol=1e-4, rtol=1e-3)
+    sampled(golden_full, "full.tap6", taps[0], atol=2e-4, rtol=1e-3)
+    sampled(golden_full, "full.tap24", taps[1], atol=2e-4, rtol=1e-3)
