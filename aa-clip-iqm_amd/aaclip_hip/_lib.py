@@ -1,0 +1,73 @@
+"""ctypes binding of libaaclip_hip.so (C ABI: include/aaclip.h).
+
+The product path has no fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  Build it with `__graft_entry__.build()` or
+`make -C aa-clip-iqm_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaaclip_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_LEAKY = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_ACT_F32 = 0, 1, 2, 3
+
+_vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+
+class BlockWeights(C.Structure):
+    """struct aaclip_block_weights (include/aaclip.h)."""
+    _fields_ = [(n, _vp) for n in (
+        "ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b",
+        "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w")]
+
+
+# name -> (restype, argtypes); every symbol include/aaclip.h declares
+SIGNATURES = {
+    "aaclip_version": (_i, []),
+    "aaclip_last_error": (C.c_char_p, []),
+    "aaclip_workspace_bytes": (_sz, [_i, _l, _i, _i, _i]),
+    "aaclip_patch_embed": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _sz, _vp]),
+    "aaclip_block": (_i, [_vp, C.POINTER(BlockWeights), _f] + [_i] * 7 + [_vp, _sz, _vp]),
+    "aaclip_tap_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
+    "aaclip_det_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
+    "aaclip_anomaly_map": (_i, [C.POINTER(_vp), _i, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "aaclip_similarity_map_train": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "aaclip_text_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "aaclip_row_head": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _sz, _vp]),
+    "aaclip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _i, _f, _vp]),
+    "aaclip_gemm": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
+    "aaclip_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the AA-CLIP HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C aa-clip-iqm_amd/csrc`). "
+                "There is no PyTorch fallback for this path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().aaclip_last_error()
+        raise RuntimeError(f"aaclip {what} failed (rc={rc}): {msg.decode() if msg else ''}")

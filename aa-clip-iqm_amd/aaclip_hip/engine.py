@@ -1,0 +1,321 @@
+"""Host-side executor: turns torch tensors into raw HIP pointers and sequences
+the C-ABI calls of libaaclip_hip.so.  PyTorch is only used for device memory,
+the current stream and parameter containers; no torch op computes anything on
+the hot path.
+
+Layout: the residual stream is batch-first, fp32, [B*L, D] contiguous for the
+whole tower (the reference permutes to LND, model/adapter.py:158; token rows are
+independent so the layout is free).  Matrix-product weights are converted once to
+the compute dtype and cached per parameter version.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, BlockWeights
+
+_TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
+_PRECISION = {"fp32": F32, "f32": F32, "fp16": F16, "f16": F16, "bf16": BF16, "amp": F16, "pure_fp16": F16,
+              "pure_bf16": BF16, "amp_bf16": BF16}
+
+
+def dtype_code(precision) -> int:
+    """Map a create_model(precision=...) string (reference model/clip.py:88,
+    model/model.py:63-69) to the arithmetic type of the matrix products.  The env
+    var AACLIP_COMPUTE overrides it for callers that cannot pass precision."""
+    env = os.environ.get("AACLIP_COMPUTE")
+    if env:
+        precision = env
+    if isinstance(precision, int):
+        return precision
+    try:
+        return _PRECISION[str(precision).lower()]
+    except KeyError:
+        raise ValueError(f"unknown precision {precision!r}; use fp32, fp16 or bf16")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return _TORCH_DT[code]
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on {t.device}; the AA-CLIP HIP path only runs on an MI355X (cuda) device "
+            "and has no CPU fallback")
+
+
+class Workspace:
+    """One growing scratch buffer per device (caller-owned as far as the C ABI
+    is concerned)."""
+    _bufs: Dict[int, torch.Tensor] = {}
+
+    @classmethod
+    def get(cls, dev: torch.device, nbytes: int) -> torch.Tensor:
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        buf = cls._bufs.get(idx)
+        if buf is None or buf.numel() < nbytes:
+            cls._bufs[idx] = None
+            buf = torch.empty(int(nbytes * 1.02) + 4096, dtype=torch.uint8, device=dev)
+            cls._bufs[idx] = buf
+        return buf
+
+    @classmethod
+    def for_rows(cls, dev: torch.device, code: int, rows: int, D: int, F: int, E: int) -> torch.Tensor:
+        n = _lib.load().aaclip_workspace_bytes(code, rows, D, F, E)
+        return cls.get(dev, n)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class WeightCache:
+    """Converted copies of matrix weights keyed by (id(param), dtype), refreshed
+    when the parameter's storage or version changes (adapters are trainable)."""
+
+    def __init__(self):
+        self._c: Dict[Tuple[int, int, str], Tuple[int, int, torch.Tensor]] = {}
+
+    def get(self, p: torch.Tensor, code: int, kind: str = "plain") -> torch.Tensor:
+        key = (id(p), code, kind)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == p.data_ptr() and hit[1] == p._version:
+            return hit[2]
+        src = p.detach()
+        if kind == "transpose":          # [in, out] parameter used as x @ P  ->  [out, in]
+            src = src.t()
+        elif kind == "conv":             # conv1.weight [D,3,ps,ps] -> [D, Kpad]
+            d = src.shape[0]
+            flat = src.reshape(d, -1)
+            kpad = (flat.shape[1] + 63) // 64 * 64
+            pad = torch.zeros(d, kpad, dtype=flat.dtype, device=flat.device)
+            pad[:, : flat.shape[1]] = flat
+            src = pad
+        out = src.to(_TORCH_DT[code]).contiguous()
+        self._c[key] = (p.data_ptr(), p._version, out)
+        return out
+
+
+CACHE = WeightCache()
+
+
+def _keep(refs: list, t: torch.Tensor) -> int:
+    refs.append(t)
+    return t.data_ptr()
+
+
+def pack_block(block, code: int, adapter_weight: Optional[torch.Tensor]) -> Tuple[BlockWeights, list]:
+    """Build the aaclip_block_weights struct for one ResidualAttentionBlock module."""
+    refs: list = []
+    w = BlockWeights()
+    w.ln1_w = _keep(refs, _f32c(block.ln_1.weight))
+    w.ln1_b = _keep(refs, _f32c(block.ln_1.bias))
+    w.qkv_w = _keep(refs, CACHE.get(block.attn.in_proj_weight, code))
+    w.qkv_b = _keep(refs, _f32c(block.attn.in_proj_bias))
+    w.out_w = _keep(refs, CACHE.get(block.attn.out_proj.weight, code))
+    w.out_b = _keep(refs, _f32c(block.attn.out_proj.bias))
+    w.ln2_w = _keep(refs, _f32c(block.ln_2.weight))
+    w.ln2_b = _keep(refs, _f32c(block.ln_2.bias))
+    w.fc_w = _keep(refs, CACHE.get(block.mlp.c_fc.weight, code))
+    w.fc_b = _keep(refs, _f32c(block.mlp.c_fc.bias))
+    w.proj_w = _keep(refs, CACHE.get(block.mlp.c_proj.weight, code))
+    w.proj_b = _keep(refs, _f32c(block.mlp.c_proj.bias))
+    w.adapter_w = _keep(refs, CACHE.get(adapter_weight, code)) if adapter_weight is not None else None
+    return w, refs
+
+
+# ----------------------------------------------------------------------------
+# path-level calls
+# ----------------------------------------------------------------------------
+def patch_embed(img: torch.Tensor, visual, code: int) -> Tuple[torch.Tensor, int, int]:
+    """reference model/adapter.py:139-156 -> x [B*L, D] fp32, returns (x, B, L)."""
+    require_gpu(img, "patch_embed")
+    lib = _lib.load()
+    img = _f32c(img)
+    B, Cc, H, W = img.shape
+    if Cc != 3:
+        raise ValueError("patch_embed expects [B,3,H,W] images")
+    ps = visual.patch_size[0]
+    D = visual.embed_dim
+    L = (H // ps) * (W // ps) + 1
+    pos = _f32c(visual.positional_embedding)
+    if pos.shape[0] != L:
+        raise RuntimeError(f"positional_embedding has {pos.shape[0]} rows but the image needs {L}")
+    x = torch.empty(B * L, D, dtype=torch.float32, device=img.device)
+    ws = Workspace.for_rows(img.device, code, B * L, D, 4 * D, 0)
+    conv_w = CACHE.get(visual.conv1.weight, code, "conv")
+    cls, lw, lb = _f32c(visual.class_embedding), _f32c(visual.ln_pre.weight), _f32c(visual.ln_pre.bias)
+    _lib.check(lib.aaclip_patch_embed(img.data_ptr(), conv_w.data_ptr(), cls.data_ptr(), pos.data_ptr(),
+                                      lw.data_ptr(), lb.data_ptr(), x.data_ptr(), B, H, W, ps, D, code,
+                                      ws.data_ptr(), ws.numel(), _stream(img.device)), "patch_embed")
+    return x, B, L
+
+
+def run_block(x: torch.Tensor, block, B: int, L: int, heads: int, code: int, causal: bool = False,
+              adapter_weight: Optional[torch.Tensor] = None, mix: float = 0.0) -> None:
+    """In place on x [B*L, D]: reference model/transformer.py:239-258 (+ adapter.py:163-170)."""
+    require_gpu(x, "block")
+    lib = _lib.load()
+    D = x.shape[1]
+    F = block.mlp.c_fc.weight.shape[0]
+    w, refs = pack_block(block, code, adapter_weight)
+    ws = Workspace.for_rows(x.device, code, B * L, D, F, 0)
+    _lib.check(lib.aaclip_block(x.data_ptr(), C.byref(w), float(mix), B, L, D, heads, F, int(causal), code,
+                                ws.data_ptr(), ws.numel(), _stream(x.device)), "block")
+    del refs
+
+
+def tap_head(x: torch.Tensor, ln_post, proj_weight: torch.Tensor, act: bool, B: int, L: int, code: int,
+             det_weight: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """reference model/adapter.py:171-184 -> (seg [B,L-1,E] unit rows, det [B,E] or None)."""
+    require_gpu(x, "tap_head")
+    lib = _lib.load()
+    D, E = x.shape[1], proj_weight.shape[0]
+    seg = torch.empty(B, L - 1, E, dtype=torch.float32, device=x.device)
+    det = torch.empty(B, E, dtype=torch.float32, device=x.device) if det_weight is not None else None
+    pw = CACHE.get(proj_weight, code)
+    dw = CACHE.get(det_weight, code) if det_weight is not None else None
+    lw, lb = _f32c(ln_post.weight), _f32c(ln_post.bias)
+    ws = Workspace.for_rows(x.device, code, B * L, D, 0, E)
+    _lib.check(lib.aaclip_tap_head(x.data_ptr(), lw.data_ptr(), lb.data_ptr(), pw.data_ptr(), int(act),
+                                   seg.data_ptr(), _ptr(dw), _ptr(det), B, L, D, E, code, ws.data_ptr(), ws.numel(),
+                                   _stream(x.device)), "tap_head")
+    return seg, det
+
+
+def row_head(x: torch.Tensor, tokens: Optional[torch.Tensor], ln, proj: torch.Tensor, kind: str, act: bool, n: int,
+             T: int, mode: int, code: int) -> torch.Tensor:
+    """LayerNorm + row pick + projection (reference model/adapter.py:297-299,
+    model/model.py:198-200, model/transformer.py:542-546).  kind: 'plain' for an
+    [E,D] Linear weight, 'transpose' for a [D,E] projection parameter."""
+    require_gpu(x, "row_head")
+    lib = _lib.load()
+    D = x.shape[1]
+    pw = CACHE.get(proj, code, kind)
+    E = pw.shape[0]
+    out = torch.empty(n, E, dtype=torch.float32, device=x.device)
+    lw, lb = _f32c(ln.weight), _f32c(ln.bias)
+    ws = Workspace.for_rows(x.device, code, n * T + n, D, 0, E)
+    tk = None
+    if tokens is not None:
+        tk = tokens.to(device=x.device, dtype=torch.int32).contiguous()
+    _lib.check(lib.aaclip_row_head(x.data_ptr(), _ptr(tk), lw.data_ptr(), lb.data_ptr(), pw.data_ptr(), int(act),
+                                   out.data_ptr(), n, T, D, E, mode, code, ws.data_ptr(), ws.numel(),
+                                   _stream(x.device)), "row_head")
+    return out
+
+
+def text_embed(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """reference model/adapter.py:277-281 -> (x [n*T, D] fp32, int32 tokens on device)."""
+    lib = _lib.load()
+    table = _f32c(table)
+    require_gpu(table, "text_embed")
+    tk = tokens.to(device=table.device, dtype=torch.int32).contiguous()
+    n, T = tk.shape
+    pos = _f32c(pos)
+    if pos.shape[0] < T:
+        raise RuntimeError("text longer than the positional embedding")
+    D = table.shape[1]
+    x = torch.empty(n * T, D, dtype=torch.float32, device=table.device)
+    _lib.check(lib.aaclip_text_embed(tk.data_ptr(), table.data_ptr(), pos.data_ptr(), x.data_ptr(), n, T, D,
+                                     table.shape[0], _stream(table.device)), "text_embed")
+    return x, tk
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+              out_code: int = F32) -> torch.Tensor:
+    """reference model/transformer.py:37-43 on any [..., D] tensor."""
+    require_gpu(x, "layernorm")
+    lib = _lib.load()
+    xc = _f32c(x)
+    D = xc.shape[-1]
+    rows = xc.numel() // D
+    out = torch.empty(xc.shape, dtype=_TORCH_DT[out_code], device=x.device)
+    w, b = _f32c(weight), _f32c(bias)
+    _lib.check(lib.aaclip_layernorm(xc.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), out_code, rows, D,
+                                    float(eps), _stream(x.device)), "layernorm")
+    return out
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: bool, code: int,
+           kind: str = "plain") -> torch.Tensor:
+    """y = act(x W^T [+ b]) through the HIP GEMM (used by SimpleAdapter/SimpleProj
+    when a caller invokes those modules directly)."""
+    require_gpu(x, "linear")
+    lib = _lib.load()
+    K = x.shape[-1]
+    w = CACHE.get(weight, code, kind)
+    N = w.shape[0]
+    a = x.detach().reshape(-1, K).to(_TORCH_DT[code]).contiguous()
+    out = torch.empty(a.shape[0], N, dtype=torch.float32, device=x.device)
+    b = _f32c(bias) if bias is not None else None
+    _lib.check(lib.aaclip_gemm(code, _lib.EPI_ACT_F32, a.data_ptr(), K, w.data_ptr(), _ptr(b), out.data_ptr(), N,
+                               a.shape[0], N, K, int(act), 0, 1.0, _stream(x.device)), "gemm")
+    return out.reshape(*x.shape[:-1], N)
+
+
+def anomaly_map(seg_tokens: Sequence[torch.Tensor], text_feature: torch.Tensor, img_size: int, ksize: int,
+                sigma: float) -> torch.Tensor:
+    """Fused reference forward_utils.py:196-213 (test=True) over all levels + the
+    level sum of test_last.py:95-100,149 -> [B, S, S]."""
+    lib = _lib.load()
+    segs = [_f32c(s) for s in seg_tokens]
+    require_gpu(segs[0], "anomaly_map")
+    B, P, E = segs[0].shape
+    g = int(round(P ** 0.5))
+    if g * g != P:
+        raise ValueError(f"{P} patches is not a square grid")
+    tf = _f32c(text_feature).to(segs[0].device)
+    if tf.dim() == 2:
+        stride = 0
+    elif tf.dim() == 3 and tf.shape[0] == B:
+        stride = E * 2
+    else:
+        raise ValueError("text feature must be [E,2] or [B,E,2]")
+    if tf.shape[-1] != 2 or tf.shape[-2] != E:
+        raise ValueError("text feature must have shape [..., E, 2]")
+    out = torch.empty(B, img_size, img_size, dtype=torch.float32, device=segs[0].device)
+    ws = Workspace.get(segs[0].device, len(segs) * B * P * 4 + 256)
+    arr = (C.c_void_p * len(segs))(*[s.data_ptr() for s in segs])
+    _lib.check(lib.aaclip_anomaly_map(arr, len(segs), tf.data_ptr(), stride, out.data_ptr(), B, g, E, img_size,
+                                      ksize, float(sigma), ws.data_ptr(), ws.numel(), _stream(out.device)),
+               "anomaly_map")
+    return out
+
+
+def similarity_map_train(seg: torch.Tensor, text_feature: torch.Tensor, img_size: int) -> torch.Tensor:
+    """reference forward_utils.py:196-216 with test=False -> [B, 2, S, S]."""
+    lib = _lib.load()
+    seg = _f32c(seg)
+    require_gpu(seg, "similarity_map")
+    B, P, E = seg.shape
+    g = int(round(P ** 0.5))
+    if g * g != P:
+        raise ValueError(f"{P} patches is not a square grid")
+    tf = _f32c(text_feature).to(seg.device)
+    stride = 0 if tf.dim() == 2 else E * 2
+    if tf.shape[-1] != 2:
+        raise AssertionError("C == 2 expected")
+    out = torch.empty(B, 2, img_size, img_size, dtype=torch.float32, device=seg.device)
+    ws = Workspace.get(seg.device, 2 * B * P * 4 + 256)
+    _lib.check(lib.aaclip_similarity_map_train(seg.data_ptr(), tf.data_ptr(), stride, out.data_ptr(), B, g, E,
+                                               img_size, ws.data_ptr(), ws.numel(), _stream(out.device)),
+               "similarity_map_train")
+    return out

@@ -58,11 +58,11 @@ class ClipCfg:
 def tiny_cfg() -> ClipCfg:
     """Reduced architecture for fast tests: same structure, head dim 64."""
     return ClipCfg(
-        embed_dim=128,
+        embed_dim=256,
         image_size=70,
         patch_size=14,
         vision=TowerCfg(256, 3, 4, 1024),
-        text=TowerCfg(128, 2, 2, 512),
+        text=TowerCfg(256, 2, 4, 1024),
         context_length=77,
         vocab_size=49408,
     )

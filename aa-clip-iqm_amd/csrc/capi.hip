@@ -1,0 +1,310 @@
+// C ABI of libaaclip_hip.so (declared in include/aaclip.h): argument checks,
+// workspace carving and kernel sequencing.  No allocation, no synchronisation:
+// every entry point only enqueues kernels on the caller's stream.
+#include <stdio.h>
+#include <string.h>
+
+#include "kernels.h"
+
+using namespace aaclip;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+#define REQUIRE(cond, msg) \
+  do {                     \
+    if (!(cond)) return fail(-1, msg); \
+  } while (0)
+
+static int finish(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
+static inline size_t esize(int dtype) { return dtype == AACLIP_F32 ? 4 : 2; }
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline bool dtype_ok(int d) { return d == AACLIP_F32 || d == AACLIP_F16 || d == AACLIP_BF16; }
+
+extern "C" {
+
+int aaclip_version(void) { return AACLIP_ABI_VERSION; }
+const char* aaclip_last_error(void) { return g_err; }
+
+size_t aaclip_workspace_bytes(int dtype, long rows, int D, int F, int E) {
+  const size_t es = esize(dtype);
+  size_t wide = (size_t)rows * (size_t)(3 * D > F ? 3 * D : F) * es;
+  size_t f32d = (size_t)rows * D * 4;
+  size_t f32e = (size_t)rows * (E > 0 ? E : 1) * 4;
+  size_t big = wide > f32d ? wide : f32d;
+  if (f32e > big) big = f32e;
+  // [narrow: rows*max(D,640)*es] [big] [rows floats] + slack
+  size_t narrow = (size_t)rows * (D > 640 ? D : 640) * es;
+  return up256(narrow) + up256(big) + up256((size_t)rows * 4) + 4096;
+}
+
+int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, long rows, int D,
+                     float eps, void* stream) {
+  REQUIRE(x && w && b && out, "layernorm: null pointer");
+  REQUIRE(dtype_ok(out_dtype), "layernorm: bad dtype");
+  REQUIRE(rows > 0, "layernorm: rows must be positive");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  launch_layernorm(out_dtype, x, w, b, out, rows, D, eps, (hipStream_t)stream);
+  return finish("layernorm");
+}
+
+int aaclip_gemm(int dtype, int epi, const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
+                int M, int N, int K, int act, int scale_cols, float scale, void* stream) {
+  REQUIRE(dtype_ok(dtype), "gemm: bad dtype");
+  REQUIRE(epi >= AACLIP_EPI_BIAS && epi <= AACLIP_EPI_ACT_F32, "gemm: bad epilogue");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias; p.out = out; p.ldc = ldc;
+  p.scale_cols = scale_cols; p.scale = scale; p.act = act;
+  const char* m = gemm_check(dtype, epi, p);
+  if (m) return fail(-1, m);
+  launch_gemm(dtype, epi, p, (hipStream_t)stream);
+  return finish("gemm");
+}
+
+int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream) {
+  REQUIRE(dtype_ok(dtype), "attention: bad dtype");
+  REQUIRE(qkv && ctx, "attention: null pointer");
+  REQUIRE(B > 0 && L > 0 && H > 0, "attention: empty problem");
+  REQUIRE(B <= 65535 && H <= 65535, "attention: grid limit");
+  launch_attention(dtype, qkv, ctx, B, L, H, causal, (hipStream_t)stream);
+  return finish("attention");
+}
+
+int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight, void* stream) {
+  REQUIRE(x && a && rows > 0, "adapter_mix: bad arguments");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  launch_adapter_mix(x, a, rows, D, weight, (hipStream_t)stream);
+  return finish("adapter_mix");
+}
+
+int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, const float* pos,
+                       const float* ln_pre_w, const float* ln_pre_b, float* x, int B, int H, int W, int ps, int D,
+                       int dtype, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(dtype_ok(dtype), "patch_embed: bad dtype");
+  REQUIRE(img && conv_w && cls && pos && ln_pre_w && ln_pre_b && x && ws, "patch_embed: null pointer");
+  REQUIRE(B > 0 && ps > 0 && H >= ps && W >= ps, "patch_embed: bad image shape");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  const int g = H / ps, gw = W / ps, P = g * gw, L = P + 1;
+  const int K = 3 * ps * ps, Kpad = (K + 63) / 64 * 64;
+  REQUIRE(Kpad <= 640, "patch_embed: 3*ps*ps must be <= 640");
+  REQUIRE(ws_bytes >= (size_t)B * P * Kpad * esize(dtype), "patch_embed: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  launch_im2col(dtype, img, ws, B, 3, H, W, ps, Kpad, s);
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = ws; p.lda = Kpad; p.W = conv_w; p.M = B * P; p.N = D; p.K = Kpad; p.out = x; p.ldc = D;
+  p.pos = pos; p.P = P; p.L = L;
+  m = gemm_check(dtype, EPI_PATCH, p);
+  if (m) return fail(-1, m);
+  launch_gemm(dtype, EPI_PATCH, p, s);
+  launch_cls_rows(x, cls, pos, B, L, D, s);
+  launch_layernorm(AACLIP_F32, x, ln_pre_w, ln_pre_b, x, (long)B * L, D, 1e-5f, s);
+  return finish("patch_embed");
+}
+
+int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int causal,
+                 int dtype, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(dtype_ok(dtype), "block: bad dtype");
+  REQUIRE(x && w && ws, "block: null pointer");
+  REQUIRE(w->ln1_w && w->ln1_b && w->qkv_w && w->qkv_b && w->out_w && w->out_b && w->ln2_w && w->ln2_b && w->fc_w &&
+              w->fc_b && w->proj_w && w->proj_b,
+          "block: null weight pointer");
+  REQUIRE(B > 0 && L > 0, "block: empty batch");
+  REQUIRE(D == 64 * H, "block: D must equal 64*H (head dim 64)");
+  REQUIRE(F % 128 == 0 && F % 64 == 0, "block: F must be a multiple of 128");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  REQUIRE(D % 128 == 0, "block: D must be a multiple of 128");
+  const long rows = (long)B * L;
+  REQUIRE(rows < (1L << 31) / 4, "block: too many rows");
+  REQUIRE(ws_bytes >= aaclip_workspace_bytes(dtype, rows, D, F, 0), "block: workspace too small");
+  const size_t es = esize(dtype);
+  char* narrow = (char*)ws;
+  char* big = narrow + up256((size_t)rows * (D > 640 ? D : 640) * es);
+  hipStream_t s = (hipStream_t)stream;
+  const int M = (int)rows;
+
+  GemmParams p;
+  // x += out_proj(attn(ln_1 x))
+  launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
+  memset(&p, 0, sizeof(p));
+  p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
+  p.ldc = 3 * D; p.scale_cols = D; p.scale = 0.125f;
+  launch_gemm(dtype, EPI_BIAS, p, s);
+  launch_attention(dtype, big, narrow, B, L, H, causal, s);
+  memset(&p, 0, sizeof(p));
+  p.A = narrow; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
+  launch_gemm(dtype, EPI_BIAS_RESID, p, s);
+  // x += c_proj(gelu(c_fc(ln_2 x)))
+  launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s);
+  memset(&p, 0, sizeof(p));
+  p.A = narrow; p.lda = D; p.W = w->fc_w; p.M = M; p.N = F; p.K = D; p.bias = w->fc_b; p.out = big; p.ldc = F;
+  launch_gemm(dtype, EPI_BIAS_GELU, p, s);
+  memset(&p, 0, sizeof(p));
+  p.A = big; p.lda = F; p.W = w->proj_w; p.M = M; p.N = D; p.K = F; p.bias = w->proj_b; p.out = x; p.ldc = D;
+  launch_gemm(dtype, EPI_BIAS_RESID, p, s);
+  // residual adapter
+  if (w->adapter_w) {
+    const void* a_in = x;
+    if (dtype != AACLIP_F32) {
+      launch_cast_rows(dtype, x, narrow, rows * D, s);
+      a_in = narrow;
+    }
+    memset(&p, 0, sizeof(p));
+    p.A = a_in; p.lda = D; p.W = w->adapter_w; p.M = M; p.N = D; p.K = D; p.out = big; p.ldc = D; p.act = 1;
+    launch_gemm(dtype, EPI_ACT_F32, p, s);
+    launch_adapter_mix(x, (const float*)big, rows, D, mix, s);
+  }
+  return finish("block");
+}
+
+static int head_common(const float* x, const float* ln_w, const float* ln_b, int B, int L, int D, int E, int dtype,
+                       void* ws, size_t ws_bytes, char** narrow, char** big, char** rowf) {
+  REQUIRE(dtype_ok(dtype), "head: bad dtype");
+  REQUIRE(x && ln_w && ln_b && ws, "head: null pointer");
+  REQUIRE(B > 0 && L > 1, "head: bad shape");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  m = row_width_check(E);
+  if (m) return fail(-1, m);
+  REQUIRE(E % 128 == 0, "head: E must be a multiple of 128");
+  const long rows = (long)B * L;
+  REQUIRE(ws_bytes >= aaclip_workspace_bytes(dtype, rows, D, 0, E), "head: workspace too small");
+  *narrow = (char*)ws;
+  *big = *narrow + up256((size_t)rows * (D > 640 ? D : 640) * esize(dtype));
+  size_t wide = (size_t)rows * (size_t)(3 * D) * esize(dtype);
+  size_t f32d = (size_t)rows * D * 4, f32e = (size_t)rows * E * 4;
+  size_t bigsz = wide > f32d ? wide : f32d;
+  if (f32e > bigsz) bigsz = f32e;
+  *rowf = *big + up256(bigsz);
+  return 0;
+}
+
+int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
+                    float* seg_out, const void* det_w, float* det_out, int B, int L, int D, int E, int dtype, void* ws,
+                    size_t ws_bytes, void* stream) {
+  char *narrow, *big, *rowf;
+  int rc = head_common(x, ln_post_w, ln_post_b, B, L, D, E, dtype, ws, ws_bytes, &narrow, &big, &rowf);
+  if (rc) return rc;
+  REQUIRE(proj_w && seg_out, "tap_head: null pointer");
+  REQUIRE(!det_w || det_out, "tap_head: det_out missing");
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)B * L;
+  launch_layernorm(dtype, x, ln_post_w, ln_post_b, narrow, rows, D, 1e-5f, s);
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = narrow; p.lda = D; p.W = proj_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
+  launch_gemm(dtype, EPI_ACT_F32, p, s);
+  launch_normalize_rows((const float*)big, seg_out, B, L, 1, E, s);
+  if (det_w) {
+    p.W = det_w;
+    launch_gemm(dtype, EPI_ACT_F32, p, s);
+    launch_det_mean((const float*)big, (float*)rowf, det_out, B, L, 1, E, s);
+  }
+  return finish("tap_head");
+}
+
+int aaclip_det_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* det_w, int act,
+                    float* det_out, int B, int L, int D, int E, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  char *narrow, *big, *rowf;
+  int rc = head_common(x, ln_post_w, ln_post_b, B, L, D, E, dtype, ws, ws_bytes, &narrow, &big, &rowf);
+  if (rc) return rc;
+  REQUIRE(det_w && det_out, "det_head: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)B * L;
+  launch_layernorm(dtype, x, ln_post_w, ln_post_b, narrow, rows, D, 1e-5f, s);
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = narrow; p.lda = D; p.W = det_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
+  launch_gemm(dtype, EPI_ACT_F32, p, s);
+  launch_det_mean((const float*)big, (float*)rowf, det_out, B, L, 1, E, s);
+  return finish("det_head");
+}
+
+int aaclip_anomaly_map(const float* const* seg, int NL, const float* anchors, long anchor_bstride, float* out, int B,
+                       int g, int E, int S, int ksize, float sigma, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(seg && anchors && out && ws, "anomaly_map: null pointer");
+  REQUIRE(NL >= 1 && NL <= 4, "anomaly_map: 1..4 levels");
+  REQUIRE(B > 0 && B <= 65535 && g >= 1 && g <= 40 && S >= 1, "anomaly_map: bad shape (grid <= 40)");
+  REQUIRE(ksize >= 1 && ksize <= 15 && ksize / 2 < g, "anomaly_map: kernel size must be 1..15 and < 2*grid");
+  REQUIRE(sigma > 0.f, "anomaly_map: sigma must be positive");
+  const char* m = row_width_check(E);
+  if (m) return fail(-1, m);
+  const int P = g * g;
+  REQUIRE(ws_bytes >= (size_t)NL * B * P * 4, "anomaly_map: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* pre = (float*)ws;
+  for (int l = 0; l < NL; ++l) {
+    REQUIRE(seg[l], "anomaly_map: null level pointer");
+    launch_patch_scores(seg[l], anchors, anchor_bstride, pre + (size_t)l * B * P, B, P, E, 0, s);
+  }
+  launch_blur_upsample(pre, out, B, g, S, NL, ksize, sigma, s);
+  return finish("anomaly_map");
+}
+
+int aaclip_similarity_map_train(const float* seg, const float* anchors, long anchor_bstride, float* out, int B, int g,
+                                int E, int S, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(seg && anchors && out && ws, "similarity_map_train: null pointer");
+  REQUIRE(B > 0 && B <= 65535 && g >= 1 && g <= 40 && S >= 1, "similarity_map_train: bad shape (grid <= 40)");
+  const char* m = row_width_check(E);
+  if (m) return fail(-1, m);
+  const int P = g * g;
+  REQUIRE(ws_bytes >= (size_t)2 * B * P * 4, "similarity_map_train: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  launch_patch_scores(seg, anchors, anchor_bstride, (float*)ws, B, P, E, 1, s);
+  launch_upsample_softmax2((const float*)ws, out, B, g, S, s);
+  return finish("similarity_map_train");
+}
+
+int aaclip_text_embed(const int32_t* tokens, const float* table, const float* pos, float* x, int n, int T, int D,
+                      int vocab, void* stream) {
+  REQUIRE(tokens && table && pos && x, "text_embed: null pointer");
+  REQUIRE(n > 0 && T > 0 && D % 4 == 0 && vocab > 0, "text_embed: bad shape");
+  launch_embed_text(tokens, table, pos, x, n, T, D, vocab, (hipStream_t)stream);
+  return finish("text_embed");
+}
+
+int aaclip_row_head(const float* x, const int32_t* tokens, const float* ln_w, const float* ln_b, const void* proj_w,
+                    int act, float* out, int n, int T, int D, int E, int mode, int dtype, void* ws, size_t ws_bytes,
+                    void* stream) {
+  REQUIRE(dtype_ok(dtype), "row_head: bad dtype");
+  REQUIRE(x && ln_w && ln_b && proj_w && out && ws, "row_head: null pointer");
+  REQUIRE(mode == 1 || tokens, "row_head: tokens required for EOT mode");
+  REQUIRE(n > 0 && T > 0, "row_head: bad shape");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  REQUIRE(E % 128 == 0, "row_head: E must be a multiple of 128");
+  const size_t es = esize(dtype);
+  const long rows = (long)n * T;
+  size_t need = up256((size_t)rows * D * es) + up256((size_t)n * D * es);
+  REQUIRE(ws_bytes >= need, "row_head: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  char* ln_out = (char*)ws;
+  char* picked = ln_out + up256((size_t)rows * D * es);
+  launch_layernorm(dtype, x, ln_w, ln_b, ln_out, rows, D, 1e-5f, s);
+  launch_gather_rows(dtype, ln_out, picked, tokens, n, T, D, mode, s);
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = picked; p.lda = D; p.W = proj_w; p.M = n; p.N = E; p.K = D; p.out = out; p.ldc = E; p.act = act;
+  const char* gm = gemm_check(dtype, EPI_ACT_F32, p);
+  if (gm) return fail(-1, gm);
+  launch_gemm(dtype, EPI_ACT_F32, p, s);
+  return finish("row_head");
+}
+
+}  // extern "C"

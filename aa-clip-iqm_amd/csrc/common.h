@@ -1,0 +1,107 @@
+// Shared device helpers for the AA-CLIP gfx950 kernels.
+// Written for CDNA4 only: 64-lane waves, MFMA 32x32x16 (f16/bf16), 32x32x2 (f32),
+// 160 KiB LDS, global->LDS DMA.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define AACLIP_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- dtype traits
+template <typename T> struct Elem;
+template <> struct Elem<f16> {
+  typedef f16x8 vec8;
+  typedef f16x4 vec4;
+  static AACLIP_DEV f32x16 mma32(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<bf16> {
+  typedef bf16x8 vec8;
+  typedef bf16x4 vec4;
+  static AACLIP_DEV f32x16 mma32(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> AACLIP_DEV T from_float(float v) { return (T)v; }
+template <typename T> AACLIP_DEV float to_float(T v) { return (float)v; }
+
+// ------------------------------------------------------------ wave reductions
+AACLIP_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+AACLIP_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------- LDS tile addressing
+// A staged tile is R rows of 128 bytes (64 sixteen-bit elements).  Two rows form
+// one 256-byte LDS bank row of sixteen 16-byte slots.  The slot of (row, chunk)
+// is XOR-swizzled so that
+//   * the ds_read_b128 fragment read of an MFMA operand (16 lanes of a lane
+//     group = 16 different rows, same chunk) touches 16 different slots, and
+//   * the ds_read_b64_tr_b16 transposed read (4 rows x 4 chunks per 32-lane
+//     half) touches 32 different 8-byte banks.
+// swz() swaps bits 0 and 2 of the row-pair index: bit 0 of the pair index must
+// move the slot by 4 for the transposed read, while any bijection works for the
+// row read.  (Checked by tools/lds_bank_model.py against the guide's bank rules.)
+AACLIP_DEV int swz16(int rp) { return (rp & 0xA) | ((rp & 1) << 2) | ((rp >> 2) & 1); }
+
+// byte offset inside a tile of element-chunk (row, chunk), chunk = 16-byte unit 0..7
+AACLIP_DEV int tile_off(int row, int chunk) {
+  int rp = row >> 1;
+  int slot = (((row & 1) << 3) | chunk) ^ swz16(rp & 15);
+  return rp * 256 + slot * 16;
+}
+
+// Inverse map used on the SOURCE side of the LDS DMA (the DMA writes LDS
+// linearly: slot p = wave-instruction base + lane): which (row, chunk) must the
+// lane that lands in linear slot p fetch.
+AACLIP_DEV void tile_src(int p, int& row, int& chunk) {
+  int rp = p >> 4;
+  int s = (p & 15) ^ swz16(rp & 15);
+  row = rp * 2 + (s >> 3);
+  chunk = s & 7;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// 16-byte global -> LDS DMA.  lds_base must be wave-uniform; lane i lands at
+// lds_base + 16*i.
+AACLIP_DEV void glds16(const void* gsrc, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_base, 16, 0, 0);
+}
+
+AACLIP_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// XCD-aware bijective remap of a 1-D workgroup id (guide T1): workgroups that
+// share an XCD (id % 8 equal) get a contiguous chunk of the tile list so that
+// neighbouring tiles hit the same L2.
+AACLIP_DEV int xcd_remap(int id, int n) {
+  int q = n >> 3, r = n & 7, x = id & 7, j = id >> 3;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + j;
+}
+
+// exact-erf GELU (nn.GELU default), reference model/model.py:84
+AACLIP_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+AACLIP_DEV float leaky(float x) { return x >= 0.f ? x : 0.01f * x; }

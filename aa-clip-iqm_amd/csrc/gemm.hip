@@ -1,0 +1,265 @@
+// NT GEMM with fused epilogues for the AA-CLIP towers on gfx950.
+//
+//   C[M,N] = A[M,K] . W[N,K]^T      (W is the nn.Linear weight as stored: [out,in])
+//
+// 16-bit operands (f16 / bf16), fp32 accumulate on v_mfma_f32_32x32x16:
+//   128x128x64 block tile, 4 waves (2x2), 64x64 per wave, two LDS stages filled
+//   by the 16-byte global->LDS DMA with the XOR-swizzled tile image of common.h,
+//   one barrier per K tile, XCD-aware tile order.
+// fp32 operands: exact-fp32 v_mfma_f32_32x32x2_f32 kernel (parity path).
+//
+// Epilogues (what the reference does right after each Linear):
+//   EPI_BIAS       out_T = acc + bias, columns < scale_cols scaled (q * hd^-1/2,
+//                  nn.MultiheadAttention, reference model/transformer.py:200,237)
+//   EPI_BIAS_GELU  out_T = gelu_erf(acc + bias)          (mlp.c_fc, transformer.py:211-219)
+//   EPI_BIAS_RESID x_f32 += acc + bias                    (out_proj / c_proj + residual, :256-257)
+//   EPI_ACT_F32    out_f32 = act(acc [+ bias])            (adapters, seg/det proj: adapter_modules.py:6-26)
+//   EPI_PATCH      x_f32[b*L+1+p] = acc + pos[1+p]        (conv1 as GEMM + positional, adapter.py:139-153)
+#include "common.h"
+#include "kernels.h"
+
+namespace aaclip {
+
+template <int EPI, typename TOut>
+AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
+  if (EPI == EPI_BIAS) {
+    v += p.bias[col];
+    if (col < p.scale_cols) v *= p.scale;
+    ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
+  } else if (EPI == EPI_BIAS_GELU) {
+    v = gelu_erf(v + p.bias[col]);
+    ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
+  } else if (EPI == EPI_BIAS_RESID) {
+    float* x = (float*)p.out + (long)row * p.ldc + col;
+    *x = *x + (v + p.bias[col]);
+  } else if (EPI == EPI_ACT_F32) {
+    if (p.bias) v += p.bias[col];
+    if (p.act == 1) v = leaky(v);
+    ((float*)p.out)[(long)row * p.ldc + col] = v;
+  } else if (EPI == EPI_PATCH) {
+    int b = row / p.P, pi = row - b * p.P;
+    long orow = (long)b * p.L + 1 + pi;
+    ((float*)p.out)[orow * p.ldc + col] = v + p.pos[(long)(1 + pi) * p.N + col];
+  }
+}
+
+// ------------------------------------------------------------------ 16-bit
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[65536];  // 2 stages x (A 16K + W 16K)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = p.N >> 7;
+  const int tiles_m = (p.M + 127) >> 7;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+
+  // --- DMA source pointers: 4 wave-instructions of 1 KiB for A and 4 for W per stage
+  const T* asrc[4];
+  const T* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int row, chunk;
+    tile_src((wave * 4 + j) * 64 + lane, row, chunk);
+    int ar = tm * 128 + row;
+    ar = ar < p.M ? ar : p.M - 1;
+    asrc[j] = (const T*)p.A + (long)ar * p.lda + chunk * 8;
+    wsrc[j] = (const T*)p.W + (long)(tn * 128 + row) * p.K + chunk * 8;
+  }
+  // --- fragment read offsets inside a tile
+  int aoff[2][4], boff[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      aoff[i][ks] = tile_off(wr * 64 + i * 32 + r, 2 * ks + h);
+      boff[i][ks] = 16384 + tile_off(wc * 64 + i * 32 + r, 2 * ks + h);
+    }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 6;
+  auto stage = [&](int s, int kt) {
+    char* base = smem + s * 32768 + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(asrc[j] + kt * 64, base + j * 1024);
+      glds16(wsrc[j] + kt * 64, base + 16384 + j * 1024);
+    }
+  };
+
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sb = smem + cur * 32768;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      vec8 a0 = *(const vec8*)(sb + aoff[0][ks]);
+      vec8 a1 = *(const vec8*)(sb + aoff[1][ks]);
+      vec8 b0 = *(const vec8*)(sb + boff[0][ks]);
+      vec8 b1 = *(const vec8*)(sb + boff[1][ks]);
+      acc[0][0] = Elem<T>::mma32(a0, b0, acc[0][0]);
+      acc[0][1] = Elem<T>::mma32(a0, b1, acc[0][1]);
+      acc[1][0] = Elem<T>::mma32(a1, b0, acc[1][0]);
+      acc[1][1] = Elem<T>::mma32(a1, b1, acc[1][1]);
+    }
+    wait_vm0();
+    __syncthreads();
+  }
+
+  // --- epilogue: lane holds column r of each 32x32 sub-tile, rows (e&3)+8(e>>2)+4h
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * 128 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < p.M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = tn * 128 + wc * 64 + j * 32 + r;
+          epi_store<EPI, T>(p, row, col, acc[i][j][e]);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------ fp32
+// Exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm32_kernel(GemmParams p) {
+  constexpr int LD = 132;
+  __shared__ float As[16 * LD];
+  __shared__ float Ws[16 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = p.N >> 7;
+  const int tiles_m = (p.M + 127) >> 7;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+
+  const float* ap[2];
+  const float* wp[2];
+  int srow[2], sk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int f = tid + 256 * j;
+    srow[j] = f >> 2;
+    sk[j] = (f & 3) * 4;
+    int ar = tm * 128 + srow[j];
+    ar = ar < p.M ? ar : p.M - 1;
+    ap[j] = (const float*)p.A + (long)ar * p.lda + sk[j];
+    wp[j] = (const float*)p.W + (long)(tn * 128 + srow[j]) * p.K + sk[j];
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 4;
+  f32x4 ra[2], rw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ra[j] = *(const f32x4*)(ap[j]);
+    rw[j] = *(const f32x4*)(wp[j]);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        As[(sk[j] + e) * LD + srow[j]] = ra[j][e];
+        Ws[(sk[j] + e) * LD + srow[j]] = rw[j][e];
+      }
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ra[j] = *(const f32x4*)(ap[j] + (kt + 1) * 16);
+        rw[j] = *(const f32x4*)(wp[j] + (kt + 1) * 16);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k = 2 * ks + h;
+      float a0 = As[k * LD + wr * 64 + r], a1 = As[k * LD + wr * 64 + 32 + r];
+      float b0 = Ws[k * LD + wc * 64 + r], b1 = Ws[k * LD + wc * 64 + 32 + r];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * 128 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < p.M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = tn * 128 + wc * 64 + j * 32 + r;
+          epi_store<EPI, float>(p, row, col, acc[i][j][e]);
+        }
+      }
+    }
+}
+
+template <typename T>
+static void launch16(int epi, const GemmParams& p, dim3 g, hipStream_t s) {
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_GELU>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_RESID>), g, dim3(256), 0, s, p); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_ACT_F32>), g, dim3(256), 0, s, p); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH>), g, dim3(256), 0, s, p); break;
+  }
+}
+
+const char* gemm_check(int dtype, int epi, const GemmParams& p) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
+  if (p.N % 128) return "gemm: N must be a multiple of 128";
+  if (p.K % (dtype == AACLIP_F32 ? 16 : 64)) return "gemm: K must be a multiple of 64 (16 for f32)";
+  if (p.lda % 8 || p.ldc % 2) return "gemm: lda must be a multiple of 8, ldc of 2";
+  if (epi < 0 || epi > EPI_PATCH) return "gemm: unknown epilogue";
+  if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID) && !p.bias) return "gemm: bias required";
+  if (epi == EPI_PATCH && (!p.pos || p.P <= 0 || p.L <= p.P)) return "gemm: patch epilogue needs pos, P, L";
+  if (!p.A || !p.W || !p.out) return "gemm: null pointer";
+  return nullptr;
+}
+
+void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+  const int tiles = ((p.M + 127) / 128) * (p.N / 128);
+  dim3 g(tiles);
+  if (dtype == AACLIP_F16) {
+    launch16<f16>(epi, p, g, s);
+  } else if (dtype == AACLIP_BF16) {
+    launch16<bf16>(epi, p, g, s);
+  } else {
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS>), g, dim3(256), 0, s, p); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS_GELU>), g, dim3(256), 0, s, p); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS_RESID>), g, dim3(256), 0, s, p); break;
+      case EPI_ACT_F32: hipLaunchKernelGGL((gemm32_kernel<EPI_ACT_F32>), g, dim3(256), 0, s, p); break;
+      case EPI_PATCH: hipLaunchKernelGGL((gemm32_kernel<EPI_PATCH>), g, dim3(256), 0, s, p); break;
+    }
+  }
+}
+
+}  // namespace aaclip

@@ -1,0 +1,58 @@
+// Internal launch interface between the C-ABI (capi.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aaclip.h"
+
+namespace aaclip {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_ACT_F32 = 3, EPI_PATCH = 4 };
+
+struct GemmParams {
+  const void* A;  // [M, lda] compute dtype
+  long lda;
+  const void* W;  // [N, K] compute dtype
+  int M, N, K;
+  const float* bias;  // [N] fp32 or null
+  void* out;          // compute dtype or fp32, by epilogue
+  long ldc;
+  int scale_cols;  // EPI_BIAS: columns < scale_cols are multiplied by scale
+  float scale;
+  int act;           // EPI_ACT_F32: 0 none, 1 LeakyReLU(0.01)
+  const float* pos;  // EPI_PATCH: positional embedding [L, N]
+  int P, L;          // EPI_PATCH: patches per image, tokens per image
+};
+
+const char* gemm_check(int dtype, int epi, const GemmParams& p);
+void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s);
+
+// fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]
+void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, hipStream_t s);
+
+// row ops (rowops.hip); D in {256, 768, 1024}
+const char* row_width_check(int D);
+void launch_layernorm(int out_dtype, const float* x, const float* w, const float* b, void* out, long rows, int D,
+                      float eps, hipStream_t s);
+void launch_adapter_mix(float* x, const float* a, long rows, int D, float weight, hipStream_t s);
+void launch_im2col(int dtype, const float* img, void* cols, int B, int C, int H, int W, int ps, int Kpad,
+                   hipStream_t s);
+void launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s);
+void launch_embed_text(const int32_t* tokens, const float* table, const float* pos, float* x, int n, int T, int D,
+                       int vocab, hipStream_t s);
+void launch_gather_rows(int dtype, const void* src, void* dst, const int32_t* tokens, int n, int T, int D, int mode,
+                        hipStream_t s);
+void launch_normalize_rows(const float* src, float* dst, int B, int L, int skip, int E, hipStream_t s);
+void launch_det_mean(const float* src, float* rowinv, float* dst, int B, int L, int skip, int E, hipStream_t s);
+
+// anomaly map (anomaly_map.hip)
+// mode 0: test-mode map m = (s1 + 1 - s0)/2 -> pre [B, P]; mode 1: raw scores -> [B, 2, P]
+void launch_patch_scores(const float* seg, const float* anchors, long anchor_bstride, float* pre, int B, int P, int E,
+                         int mode, hipStream_t s);
+// pre [NL][B, g, g] -> out [B, S, S] = sum over levels of upsample(blur(pre_l)); NL <= 4, g <= 40
+void launch_blur_upsample(const float* pre, float* out, int B, int g, int S, int NL, int ksize, float sigma,
+                          hipStream_t s);
+void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int S, hipStream_t s);
+void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
+
+}  // namespace aaclip

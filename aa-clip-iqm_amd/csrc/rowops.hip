@@ -1,0 +1,320 @@
+// Row-wise (HBM-bound) kernels of the AA-CLIP path: one 64-lane wave owns one
+// token row, keeps it in registers (16-byte coalesced loads), and reduces with
+// cross-lane shuffles.  Row widths are 256 / 768 / 1024 (NCH = D/256 float4
+// chunks per lane).
+#include "common.h"
+#include "kernels.h"
+
+namespace aaclip {
+
+const char* row_width_check(int D) {
+  if (D == 256 || D == 512 || D == 768 || D == 1024) return nullptr;
+  return "row width must be 256, 512, 768 or 1024";
+}
+
+template <int NCH>
+AACLIP_DEV void load_row(const float* p, int lane, f32x4 (&v)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) v[c] = *(const f32x4*)(p + (c * 64 + lane) * 4);
+}
+
+template <typename T>
+AACLIP_DEV void store4(T* p, f32x4 v);
+template <>
+AACLIP_DEV void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <>
+AACLIP_DEV void store4<f16>(f16* p, f32x4 v) {
+  f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *(f16x4*)p = o;
+}
+template <>
+AACLIP_DEV void store4<bf16>(bf16* p, f32x4 v) {
+  bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  *(bf16x4*)p = o;
+}
+
+// LayerNorm over the last dim, reference model/transformer.py:37-43 (eps 1e-5),
+// two-pass statistics in registers; out may alias x when T == float.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, T* out, long rows, float eps) {
+  constexpr int D = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[NCH];
+  load_row<NCH>(x + row * D, lane, v);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = v[c][e] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    f32x4 g = *(const f32x4*)(w + col), bb = *(const f32x4*)(b + col), y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
+    store4<T>(out + row * D + col, y);
+  }
+}
+
+template <typename T>
+static void ln_dispatch(const float* x, const float* w, const float* b, T* out, long rows, int D, float eps,
+                        hipStream_t s) {
+  dim3 g((unsigned)((rows + 3) / 4));
+  switch (D / 256) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<T, 3>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 4: hipLaunchKernelGGL((layernorm_kernel<T, 4>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+  }
+}
+
+void launch_layernorm(int out_dtype, const float* x, const float* w, const float* b, void* out, long rows, int D,
+                      float eps, hipStream_t s) {
+  if (out_dtype == AACLIP_F32) ln_dispatch<float>(x, w, b, (float*)out, rows, D, eps, s);
+  else if (out_dtype == AACLIP_F16) ln_dispatch<f16>(x, w, b, (f16*)out, rows, D, eps, s);
+  else ln_dispatch<bf16>(x, w, b, (bf16*)out, rows, D, eps, s);
+}
+
+// Residual adapter mix, reference model/adapter.py:165-170 (and :290-295):
+//   a <- a * |x| / |a| per token (no eps), x <- w*a + (1-w)*x, in place on x.
+template <int NCH>
+__global__ __launch_bounds__(256) void adapter_mix_kernel(float* x, const float* __restrict__ a, long rows,
+                                                          float weight) {
+  constexpr int D = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 xv[NCH], av[NCH];
+  load_row<NCH>(x + row * D, lane, xv);
+  load_row<NCH>(a + row * D, lane, av);
+  float sx = 0.f, sa = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sx = fmaf(xv[c][e], xv[c][e], sx);
+      sa = fmaf(av[c][e], av[c][e], sa);
+    }
+  const float nx = sqrtf(wave_sum(sx)), na = sqrtf(wave_sum(sa));
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = weight * (av[c][e] * nx / na) + (1.0f - weight) * xv[c][e];
+    *(f32x4*)(x + row * D + (c * 64 + lane) * 4) = y;
+  }
+}
+
+void launch_adapter_mix(float* x, const float* a, long rows, int D, float weight, hipStream_t s) {
+  dim3 g((unsigned)((rows + 3) / 4));
+  switch (D / 256) {
+    case 1: hipLaunchKernelGGL(adapter_mix_kernel<1>, g, dim3(256), 0, s, x, a, rows, weight); break;
+    case 2: hipLaunchKernelGGL(adapter_mix_kernel<2>, g, dim3(256), 0, s, x, a, rows, weight); break;
+    case 3: hipLaunchKernelGGL(adapter_mix_kernel<3>, g, dim3(256), 0, s, x, a, rows, weight); break;
+    case 4: hipLaunchKernelGGL(adapter_mix_kernel<4>, g, dim3(256), 0, s, x, a, rows, weight); break;
+  }
+}
+
+// Unfold non-overlapping ps x ps patches of an NCHW fp32 image into GEMM rows:
+// cols[(b*g*g + py*g + px)][c*ps*ps + ky*ps + kx], zero padded to Kpad
+// (conv1 of reference model/transformer.py:359-365 as a GEMM).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int C,
+                                                     int H, int W, int ps, int Kpad) {
+  const int g = H / ps, gw = W / ps;
+  const long row = blockIdx.x;  // one patch per block
+  const int b = row / (g * gw), pi = row % (g * gw), py = pi / gw, px = pi % gw;
+  const int K = C * ps * ps;
+  for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+    float v = 0.f;
+    if (k < K) {
+      int c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
+      v = img[(((long)b * C + c) * H + py * ps + ky) * W + px * ps + kx];
+    }
+    cols[row * Kpad + k] = from_float<T>(v);
+  }
+}
+
+void launch_im2col(int dtype, const float* img, void* cols, int B, int C, int H, int W, int ps, int Kpad,
+                   hipStream_t s) {
+  dim3 g((unsigned)((long)B * (H / ps) * (W / ps)));
+  if (dtype == AACLIP_F32)
+    hipLaunchKernelGGL(im2col_kernel<float>, g, dim3(256), 0, s, img, (float*)cols, B, C, H, W, ps, Kpad);
+  else if (dtype == AACLIP_F16)
+    hipLaunchKernelGGL(im2col_kernel<f16>, g, dim3(256), 0, s, img, (f16*)cols, B, C, H, W, ps, Kpad);
+  else
+    hipLaunchKernelGGL(im2col_kernel<bf16>, g, dim3(256), 0, s, img, (bf16*)cols, B, C, H, W, ps, Kpad);
+}
+
+// x[b*L + 0] = class_embedding + positional_embedding[0]  (reference model/adapter.py:143-153)
+__global__ void cls_rows_kernel(float* x, const float* __restrict__ cls, const float* __restrict__ pos, int L, int D) {
+  const int b = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long)b * L * D + d] = cls[d] + pos[d];
+}
+void launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(B), dim3(256), 0, s, x, cls, pos, L, D);
+}
+
+// x[i*T + t] = token_embedding[tokens[i,t]] + positional_embedding[t]  (reference model/adapter.py:277-281)
+__global__ void embed_text_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
+                                  const float* __restrict__ pos, float* x, int T, int D, int vocab) {
+  const long row = blockIdx.x;
+  int id = tokens[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int t = row % T;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+    f32x4 e = *(const f32x4*)(table + (long)id * D + d), p = *(const f32x4*)(pos + (long)t * D + d);
+    *(f32x4*)(x + row * D + d) = e + p;
+  }
+}
+void launch_embed_text(const int32_t* tokens, const float* table, const float* pos, float* x, int n, int T, int D,
+                       int vocab, hipStream_t s) {
+  hipLaunchKernelGGL(embed_text_kernel, dim3(n * T), dim3(64), 0, s, tokens, table, pos, x, T, D, vocab);
+}
+
+// Row gather: mode 0 = row at argmax(tokens[i,:]) (first maximum, = EOT:
+// reference model/adapter.py:299), mode 1 = row 0 of each sequence (CLS).
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, const int32_t* __restrict__ tokens,
+                                   int Tn, int D, int mode) {
+  const int i = blockIdx.x;
+  __shared__ int pick;
+  if (threadIdx.x == 0) {
+    int best = 0;
+    if (mode == 0) {
+      int bv = tokens[(long)i * Tn];
+      for (int t = 1; t < Tn; ++t) {
+        int v = tokens[(long)i * Tn + t];
+        if (v > bv) { bv = v; best = t; }
+      }
+    }
+    pick = best;
+  }
+  __syncthreads();
+  const T* s = src + ((long)i * Tn + pick) * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) dst[(long)i * D + d] = s[d];
+}
+void launch_gather_rows(int dtype, const void* src, void* dst, const int32_t* tokens, int n, int T, int D, int mode,
+                        hipStream_t s) {
+  if (dtype == AACLIP_F32)
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(n), dim3(256), 0, s, (const float*)src, (float*)dst, tokens, T,
+                       D, mode);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<uint16_t>, dim3(n), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst,
+                       tokens, T, D, mode);
+}
+
+// F.normalize(dim=-1) (eps 1e-12) of rows [B*L, E], dropping the first `skip`
+// rows of every image (CLS): dst [B, L-skip, E]   (reference model/adapter.py:182)
+template <int NCH>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int B, int L, int skip) {
+  constexpr int E = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int P = L - skip;
+  if (orow >= (long)B * P) return;
+  const long b = orow / P, pi = orow - b * P;
+  const float* sp = src + (b * L + skip + pi) * E;
+  f32x4 v[NCH];
+  load_row<NCH>(sp, lane, v);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q = fmaf(v[c][e], v[c][e], q);
+  const float n = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = v[c][e] / n;
+    *(f32x4*)(dst + orow * E + (c * 64 + lane) * 4) = y;
+  }
+}
+void launch_normalize_rows(const float* src, float* dst, int B, int L, int skip, int E, hipStream_t s) {
+  dim3 g((unsigned)(((long)B * (L - skip) + 3) / 4));
+  switch (E / 256) {
+    case 1: hipLaunchKernelGGL(normalize_rows_kernel<1>, g, dim3(256), 0, s, src, dst, B, L, skip); break;
+    case 2: hipLaunchKernelGGL(normalize_rows_kernel<2>, g, dim3(256), 0, s, src, dst, B, L, skip); break;
+    case 3: hipLaunchKernelGGL(normalize_rows_kernel<3>, g, dim3(256), 0, s, src, dst, B, L, skip); break;
+    case 4: hipLaunchKernelGGL(normalize_rows_kernel<4>, g, dim3(256), 0, s, src, dst, B, L, skip); break;
+  }
+}
+
+// det token: F.normalize rows then mean over the patches of each image,
+// reference model/adapter.py:183-184.  Two kernels: row inverse norms, then a
+// column-parallel mean (fixed summation order -> reproducible).
+template <int NCH>
+__global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restrict__ src, float* __restrict__ inv,
+                                                          long rows) {
+  constexpr int E = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[NCH];
+  load_row<NCH>(src + row * E, lane, v);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q = fmaf(v[c][e], v[c][e], q);
+  const float n = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+  if (lane == 0) inv[row] = 1.0f / n;
+}
+__global__ void det_mean_kernel(const float* __restrict__ src, const float* __restrict__ inv, float* __restrict__ dst,
+                                int L, int skip, int E) {
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= E) return;
+  float acc = 0.f;
+  for (int t = skip; t < L; ++t) {
+    const long row = (long)b * L + t;
+    acc += src[row * E + col] * inv[row];
+  }
+  dst[(long)b * E + col] = acc / (float)(L - skip);
+}
+void launch_det_mean(const float* src, float* rowinv, float* dst, int B, int L, int skip, int E, hipStream_t s) {
+  const long rows = (long)B * L;
+  dim3 g((unsigned)((rows + 3) / 4));
+  switch (E / 256) {
+    case 1: hipLaunchKernelGGL(row_invnorm_kernel<1>, g, dim3(256), 0, s, src, rowinv, rows); break;
+    case 2: hipLaunchKernelGGL(row_invnorm_kernel<2>, g, dim3(256), 0, s, src, rowinv, rows); break;
+    case 3: hipLaunchKernelGGL(row_invnorm_kernel<3>, g, dim3(256), 0, s, src, rowinv, rows); break;
+    case 4: hipLaunchKernelGGL(row_invnorm_kernel<4>, g, dim3(256), 0, s, src, rowinv, rows); break;
+  }
+  hipLaunchKernelGGL(det_mean_kernel, dim3((E + 63) / 64, B), dim3(64), 0, s, src, rowinv, dst, L, skip, E);
+}
+
+}  // namespace aaclip
+
+namespace aaclip {
+// fp32 -> compute dtype copy (adapter GEMM input is the raw residual stream)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    store4<T>(dst + i * 4, *(const f32x4*)(src + i * 4));
+}
+void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s) {
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == AACLIP_F16)
+    hipLaunchKernelGGL(cast_rows_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, s, src, (f16*)dst, n4);
+  else if (dtype == AACLIP_BF16)
+    hipLaunchKernelGGL(cast_rows_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, src, (bf16*)dst, n4);
+  else
+    hipLaunchKernelGGL(cast_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, src, (float*)dst, n4);
+}
+}  // namespace aaclip

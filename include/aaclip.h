@@ -1,0 +1,139 @@
+/* aaclip.h -- C ABI of libaaclip_hip.so: the MI355X (gfx950) AA-CLIP inference hot path.
+ *
+ * The reference (liu20050510/AA-CLIP-IQM) has no FFI of its own: its callers reach
+ * into nn.Module attributes.  This header is therefore the boundary a binding for
+ * the reference's hot path would use; every entry point names the reference code it
+ * replaces (file:line under the reference root).  INTEGRATION.md shows the ctypes
+ * stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers into memory owned by the caller (torch tensors
+ *    on the Python side); the library allocates nothing it returns.  Scratch is a
+ *    caller-provided workspace (aaclip_workspace_bytes).
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it.
+ *  - `dtype` selects the arithmetic type of the matrix products:
+ *      AACLIP_F32  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), parity path
+ *      AACLIP_F16 / AACLIP_BF16  16-bit operands, fp32 accumulate (v_mfma_f32_32x32x16)
+ *    Weights of matrix products are passed already converted to `dtype`, row-major
+ *    [out_features, in_features] exactly like nn.Linear.weight.  LayerNorm
+ *    parameters, biases, embeddings, the residual stream and all outputs are fp32.
+ *  - Return value: 0 on success, negative on error; aaclip_last_error() returns a
+ *    thread-local message.  No exceptions cross the ABI.
+ */
+#ifndef AACLIP_H
+#define AACLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AACLIP_ABI_VERSION 1
+
+enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2 };
+enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1 };
+/* generic GEMM epilogues (aaclip_gemm) */
+enum { AACLIP_EPI_BIAS = 0, AACLIP_EPI_BIAS_GELU = 1, AACLIP_EPI_BIAS_RESID = 2, AACLIP_EPI_ACT_F32 = 3 };
+
+int aaclip_version(void);
+const char* aaclip_last_error(void);
+
+/* Scratch needed by any call below for `rows` token rows of width D, MLP width F,
+ * embed width E (pass the largest you will use). */
+size_t aaclip_workspace_bytes(int dtype, long rows, int D, int F, int E);
+
+/* Weights of one ResidualAttentionBlock (reference model/transformer.py:183-258)
+ * plus the optional residual adapter applied after it (model/adapter.py:163-170). */
+typedef struct aaclip_block_weights {
+  const float* ln1_w;   /* [D] */
+  const float* ln1_b;
+  const void* qkv_w;    /* attn.in_proj_weight [3D, D], dtype */
+  const float* qkv_b;   /* attn.in_proj_bias [3D] */
+  const void* out_w;    /* attn.out_proj.weight [D, D], dtype */
+  const float* out_b;
+  const float* ln2_w;
+  const float* ln2_b;
+  const void* fc_w;     /* mlp.c_fc.weight [F, D], dtype */
+  const float* fc_b;
+  const void* proj_w;   /* mlp.c_proj.weight [D, F], dtype */
+  const float* proj_b;
+  const void* adapter_w; /* SimpleAdapter fc.0.weight [D, D], dtype; NULL = no adapter */
+} aaclip_block_weights;
+
+/* Patch embedding + class token + positional embedding + ln_pre.
+ * Replaces reference model/adapter.py:139-156 (== model/transformer.py:507-526).
+ * img [B,3,H,W] fp32 NCHW; conv_w = conv1.weight reshaped [D, 3*ps*ps] and zero
+ * padded to [D, Kpad], Kpad = round_up(3*ps*ps, 64), dtype; pos [L, D];
+ * x (out) [B*L, D] fp32 with L = (H/ps)*(W/ps)+1. */
+int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, const float* pos,
+                       const float* ln_pre_w, const float* ln_pre_b, float* x, int B, int H, int W, int ps, int D,
+                       int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* One pre-LN residual attention block, in place on the fp32 residual stream
+ * x [B*L, D]:  x += out_proj(MHA(ln_1 x));  x += c_proj(gelu_erf(c_fc(ln_2 x)));
+ * then, if w->adapter_w: a = LeakyReLU(x Wa^T); x = mix*a*|x|/|a| + (1-mix)*x.
+ * Replaces ResidualAttentionBlock.forward (reference model/transformer.py:239-258,
+ * nn.MultiheadAttention at :200,237) and the adapter lines model/adapter.py:162-170
+ * (visual, causal=0) / :285-295 (text, causal=1: mask of model/transformer.py:629-635).
+ * H heads of 64; D = 64*H. */
+int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int causal,
+                 int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* Tap head: ln_post -> seg_proj (Linear no bias [+LeakyReLU]) -> F.normalize, CLS row
+ * dropped.  Replaces reference model/adapter.py:171-182.  x [B*L, D] fp32 (tap of the
+ * residual stream); proj_w [E, D] dtype; seg_out [B, L-1, E] fp32 unit rows.
+ * If det_w != NULL also writes det_out [B, E] = mean over patches of
+ * F.normalize(det_proj(ln_post x)) (model/adapter.py:183-184). */
+int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
+                    float* seg_out, const void* det_w, float* det_out, int B, int L, int D, int E, int dtype, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* Detection head alone (reference model/adapter.py:183-184). */
+int aaclip_det_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* det_w, int act,
+                    float* det_out, int B, int L, int D, int E, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* Fused test-mode anomaly map over NL tap levels: per level s = 100 f.t,
+ * m = (s1 + 1 - s0)/2, Gaussian blur (ksize, sigma; reflect), bilinear
+ * align_corners=True to S x S; out [B,S,S] = sum over levels.  Replaces
+ * calculate_similarity_map(test=True) (reference forward_utils.py:196-213) applied per
+ * level and the level sum of test_last.py:95-100,149.  seg[l] [B, g*g, E] unit rows;
+ * anchors [E,2] (anchor_bstride 0) or [B,E,2] (anchor_bstride E*2).  NL <= 4, g <= 40.
+ * ksize 1 skips the blur. */
+int aaclip_anomaly_map(const float* const* seg, int NL, const float* anchors, long anchor_bstride, float* out, int B,
+                       int g, int E, int S, int ksize, float sigma, void* ws, size_t ws_bytes, void* stream);
+
+/* Train-mode similarity map: bilinear on both channels then softmax over C=2,
+ * out [B,2,S,S].  Replaces calculate_similarity_map(test=False)
+ * (reference forward_utils.py:199-203,211-215). */
+int aaclip_similarity_map_train(const float* seg, const float* anchors, long anchor_bstride, float* out, int B, int g,
+                                int E, int S, void* ws, size_t ws_bytes, void* stream);
+
+/* Text embedding: x[i*T+t] = token_embedding[tokens[i,t]] + positional_embedding[t].
+ * Replaces reference model/adapter.py:277-281 (model/model.py:192-194). */
+int aaclip_text_embed(const int32_t* tokens, const float* table, const float* pos, float* x, int n, int T, int D,
+                      int vocab, void* stream);
+
+/* Row head: LayerNorm, pick one row per sequence, project.
+ *   mode 0: row at argmax(tokens[i,:]) (EOT) -- ln_final + text_adapter[-1] / text_projection,
+ *           reference model/adapter.py:297-299 and model/model.py:198-200
+ *   mode 1: row 0 (CLS) -- ln_post + visual.proj, reference model/transformer.py:542-546
+ * x [n*T, D] fp32; proj_w [E, D] dtype (pass text_projection / visual.proj transposed);
+ * out [n, E] fp32. */
+int aaclip_row_head(const float* x, const int32_t* tokens, const float* ln_w, const float* ln_b, const void* proj_w,
+                    int act, float* out, int n, int T, int D, int E, int mode, int dtype, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* Building blocks, exported for unit parity tests and for callers that fuse differently. */
+int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, long rows, int D,
+                     float eps, void* stream);
+int aaclip_gemm(int dtype, int epi, const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
+                int M, int N, int K, int act, int scale_cols, float scale, void* stream);
+int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream);
+int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AACLIP_H */

@@ -26,9 +26,17 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, os.path.join(REPO, "aa-clip-iqm_amd"))
 
-from aaclip_hip import synth  # noqa: E402
+# Load the build's weight generator by file path: the build's own `model/` and
+# `dataset/` packages must NOT be importable here, or they would shadow the
+# reference's (which are namespace packages without __init__.py).
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "aaclip_synth", os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+sys.modules["aaclip_synth"] = synth
+_spec.loader.exec_module(synth)
 
 
 def _stub_and_import_reference():
@@ -55,6 +63,8 @@ def _stub_and_import_reference():
     import model.tokenizer as ref_tok
     import forward_utils as ref_fu
     import dataset.constants as ref_const
+    for m in (ref_adapter, ref_clip, ref_model, ref_tok, ref_fu, ref_const):
+        assert m.__file__.startswith(REF + "/"), f"{m.__name__} was not imported from the reference: {m.__file__}"
     return ref_adapter, ref_clip, ref_model, ref_tok, ref_fu, ref_const
 
 
@@ -157,8 +167,8 @@ def main():
     g["resize.in"] = pe.numpy()
     g["resize.out"] = holder["visual.positional_embedding"].numpy()
     # similarity map pieces on small synthetic unit features
-    pf = torch.nn.functional.normalize(synth.randn("golden.pf", (2, 25, 128), 1.0, 7), dim=-1)
-    tf = torch.nn.functional.normalize(synth.randn("golden.tf", (2, 128, 2), 1.0, 7), dim=1)
+    pf = torch.nn.functional.normalize(synth.randn("golden.pf", (2, 25, 256), 1.0, 7), dim=-1)
+    tf = torch.nn.functional.normalize(synth.randn("golden.tf", (2, 256, 2), 1.0, 7), dim=1)
     g["map.pf"] = pf.numpy()
     g["map.tf"] = tf.numpy()
     g["map.train"] = FU.calculate_similarity_map(pf, tf, 70, test=False).numpy()
