@@ -44,6 +44,8 @@ SIGNATURES = {
     "aaclip_gemm": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
     "aaclip_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
+    "aaclip_profile_begin": (_i, [C.c_uint, _i]),
+    "aaclip_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -87,17 +88,20 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 class WeightCache:
-    """Converted copies of matrix weights keyed by (id(param), dtype), refreshed
-    when the parameter's storage or version changes (adapters are trainable)."""
+    """Converted copies of matrix weights, one per (parameter object, dtype, kind),
+    refreshed when the parameter's storage or version changes (adapters are
+    trainable).  Entries hold a weak reference to the parameter: id() values and
+    device addresses are recycled once a model is freed, so identity is checked
+    on the object itself and dead entries are dropped."""
 
     def __init__(self):
-        self._c: Dict[Tuple[int, int, str], Tuple[int, int, torch.Tensor]] = {}
+        self._c: Dict[Tuple[int, int, str], tuple] = {}
 
     def get(self, p: torch.Tensor, code: int, kind: str = "plain") -> torch.Tensor:
         key = (id(p), code, kind)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == p.data_ptr() and hit[1] == p._version:
-            return hit[2]
+        if hit is not None and hit[0]() is p and hit[1] == p.data_ptr() and hit[2] == p._version:
+            return hit[3]
         src = p.detach()
         if kind == "transpose":          # [in, out] parameter used as x @ P  ->  [out, in]
             src = src.t()
@@ -109,7 +113,14 @@ class WeightCache:
             pad[:, : flat.shape[1]] = flat
             src = pad
         out = src.to(_TORCH_DT[code]).contiguous()
-        self._c[key] = (p.data_ptr(), p._version, out)
+        cache = self._c
+
+        def _drop(_ref, key=key):
+            ent = cache.get(key)
+            if ent is not None and ent[0] is _ref:
+                del cache[key]
+
+        self._c[key] = (weakref.ref(p, _drop), p.data_ptr(), p._version, out)
         return out
 
 

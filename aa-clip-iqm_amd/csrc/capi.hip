@@ -2,6 +2,7 @@
 // workspace carving and kernel sequencing.  No allocation, no synchronisation:
 // every entry point only enqueues kernels on the caller's stream.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -28,11 +29,64 @@ static int finish(const char* what) {
   return 0;
 }
 
+// ---- optional in-stream timing of tagged kernels (bench.py roofline leg) ----
+// Tags: 0 ln, 1 qkv gemm, 2 attention, 3 out_proj gemm, 4 c_fc gemm, 5 c_proj gemm, 6 adapter
+struct ProfSlot { hipEvent_t a, b; int tag; };
+static ProfSlot* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+static unsigned g_prof_mask = 0;
+struct ProfScope {
+  int idx;
+  hipStream_t s;
+  ProfScope(int tag, hipStream_t st) : idx(-1), s(st) {
+    if (g_prof_mask & (1u << tag)) {
+      if (g_prof_n < g_prof_cap) {
+        idx = g_prof_n++;
+        g_prof[idx].tag = tag;
+        (void)hipEventRecord(g_prof[idx].a, s);
+      }
+    }
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s);
+  }
+};
+
 static inline size_t esize(int dtype) { return dtype == AACLIP_F32 ? 4 : 2; }
 static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline bool dtype_ok(int d) { return d == AACLIP_F32 || d == AACLIP_F16 || d == AACLIP_BF16; }
 
 extern "C" {
+
+int aaclip_profile_begin(unsigned tag_mask, int capacity) {
+  if (capacity > g_prof_cap) {
+    ProfSlot* n = (ProfSlot*)realloc(g_prof, sizeof(ProfSlot) * capacity);
+    if (!n) return fail(-3, "profile: out of memory");
+    g_prof = n;
+    for (int i = g_prof_cap; i < capacity; ++i) {
+      if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess)
+        return fail(-2, "profile: hipEventCreate failed");
+    }
+    g_prof_cap = capacity;
+  }
+  g_prof_n = 0;
+  g_prof_mask = tag_mask;
+  return 0;
+}
+
+int aaclip_profile_end(float* ms, int* tags, int max_n) {
+  g_prof_mask = 0;
+  int n = g_prof_n < max_n ? g_prof_n : max_n;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof[i].b) != hipSuccess) return fail(-2, "profile: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) return fail(-2, "profile: elapsed failed");
+    ms[i] = t;
+    tags[i] = g_prof[i].tag;
+  }
+  g_prof_n = 0;
+  return n;
+}
 
 int aaclip_version(void) { return AACLIP_ABI_VERSION; }
 const char* aaclip_last_error(void) { return g_err; }
@@ -141,25 +195,26 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
 
   GemmParams p;
   // x += out_proj(attn(ln_1 x))
-  launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
+  { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
   memset(&p, 0, sizeof(p));
   p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
   p.ldc = 3 * D; p.scale_cols = D; p.scale = 0.125f;
-  launch_gemm(dtype, EPI_BIAS, p, s);
-  launch_attention(dtype, big, narrow, B, L, H, causal, s);
+  { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
+  { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, causal, s); }
   memset(&p, 0, sizeof(p));
   p.A = narrow; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
-  launch_gemm(dtype, EPI_BIAS_RESID, p, s);
+  { ProfScope ps(3, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
   // x += c_proj(gelu(c_fc(ln_2 x)))
-  launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s);
+  { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s); }
   memset(&p, 0, sizeof(p));
   p.A = narrow; p.lda = D; p.W = w->fc_w; p.M = M; p.N = F; p.K = D; p.bias = w->fc_b; p.out = big; p.ldc = F;
-  launch_gemm(dtype, EPI_BIAS_GELU, p, s);
+  { ProfScope ps(4, s); launch_gemm(dtype, EPI_BIAS_GELU, p, s); }
   memset(&p, 0, sizeof(p));
   p.A = big; p.lda = F; p.W = w->proj_w; p.M = M; p.N = D; p.K = F; p.bias = w->proj_b; p.out = x; p.ldc = D;
-  launch_gemm(dtype, EPI_BIAS_RESID, p, s);
+  { ProfScope ps(5, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
   // residual adapter
   if (w->adapter_w) {
+    ProfScope ps(6, s);
     const void* a_in = x;
     if (dtype != AACLIP_F32) {
       launch_cast_rows(dtype, x, narrow, rows * D, s);

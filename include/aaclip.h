@@ -125,6 +125,14 @@ int aaclip_row_head(const float* x, const int32_t* tokens, const float* ln_w, co
                     int act, float* out, int n, int T, int D, int E, int mode, int dtype, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* In-stream timing of the kernels inside aaclip_block for the benchmark's roofline leg:
+ * begin(tag_mask, capacity) arms hipEvent pairs around kernels whose tag bit is set
+ * (0 layernorm, 1 qkv gemm, 2 attention, 3 out_proj gemm, 4 c_fc gemm, 5 c_proj gemm,
+ * 6 adapter); end() synchronises the recorded events and returns how many (ms[i], tags[i])
+ * pairs it wrote.  Not part of the reference's surface; measurement only. */
+int aaclip_profile_begin(unsigned tag_mask, int capacity);
+int aaclip_profile_end(float* ms, int* tags, int max_n);
+
 /* Building blocks, exported for unit parity tests and for callers that fuse differently. */
 int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, long rows, int D,
                      float eps, void* stream);

@@ -7,7 +7,7 @@ Tolerances (written where used):
   * fp16 MFMA path ('fp16'): BASELINE.json north_star -- 1e-3 abs + 1e-2 rel --
     applied to the API outputs: unit-norm seg tokens, det token, text
     embeddings (as the cosine they feed), and anomaly maps.
-  * bf16: 8-bit mantissa, reported with a looser bound (4e-3 abs + 3e-2 rel).
+  * bf16: 8-bit mantissa; offered, not the parity path: 1e-2 abs + 5e-2 rel.
 """
 import ctypes as C
 
@@ -47,7 +47,7 @@ def assert_close(a, b, atol, rtol, what=""):
                            f"max err {err.max().item():.3e} at ref {b.flatten()[err.argmax()].item():.3e}")
 
 
-TOL = {F32: (2e-4, 1e-3), F16: (1e-3, 1e-2), BF16: (4e-3, 3e-2)}
+TOL = {F32: (2e-4, 1e-3), F16: (1e-3, 1e-2), BF16: (1e-2, 5e-2)}
 
 
 # ----------------------------------------------------------------------------
