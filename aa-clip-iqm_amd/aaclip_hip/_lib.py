@@ -44,6 +44,7 @@ SIGNATURES = {
     "aaclip_gemm": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
     "aaclip_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
+    "aaclip_set_gemm_variant": (_i, [_i]),
     "aaclip_profile_begin": (_i, [C.c_uint, _i]),
     "aaclip_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
 }
@@ -65,6 +66,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        v = os.environ.get("AACLIP_GEMM_VARIANT")
+        if v:
+            lib.aaclip_set_gemm_variant(int(v))
         _lib = lib
     return _lib
 

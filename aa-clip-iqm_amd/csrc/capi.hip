@@ -88,6 +88,11 @@ int aaclip_profile_end(float* ms, int* tags, int max_n) {
   return n;
 }
 
+int aaclip_set_gemm_variant(int v) {
+  set_gemm_variant(v);
+  return 0;
+}
+
 int aaclip_version(void) { return AACLIP_ABI_VERSION; }
 const char* aaclip_last_error(void) { return g_err; }
 

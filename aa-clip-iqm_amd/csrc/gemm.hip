@@ -244,7 +244,14 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
   return nullptr;
 }
 
+static int g_gemm_variant = 0;  // 0 auto, 1 force the 128-tile kernel, 2 force the 256-tile kernel where legal
+void set_gemm_variant(int v) { g_gemm_variant = v; }
+
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+  if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant == 2 || p.M >= 4096)) {
+    launch_gemm256(dtype, epi, p, s);
+    return;
+  }
   const int tiles = ((p.M + 127) / 128) * (p.N / 128);
   dim3 g(tiles);
   if (dtype == AACLIP_F16) {

@@ -133,6 +133,10 @@ int aaclip_row_head(const float* x, const int32_t* tokens, const float* ln_w, co
 int aaclip_profile_begin(unsigned tag_mask, int capacity);
 int aaclip_profile_end(float* ms, int* tags, int max_n);
 
+/* Kernel selection for A/B measurements: 0 = automatic (default), 1 = always the 128x128-tile
+ * GEMM, 2 = the 256x256-tile GEMM wherever its shape constraints hold. */
+int aaclip_set_gemm_variant(int v);
+
 /* Building blocks, exported for unit parity tests and for callers that fuse differently. */
 int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, long rows, int D,
                      float eps, void* stream);
