@@ -20,14 +20,33 @@
 
 namespace aaclip {
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
-                                                     int causal) {
+// LDS images of the 64-row x 128-byte K and V tiles (16-byte chunk index XOR-swizzled):
+//   K tile: chunk ^= (row>>1)&7   -> the MFMA operand ds_read_b128 (16 rows per lane group)
+//                                    is conflict-free; rows 32 apart differ by a constant
+//   V tile: chunk ^= ((row>>1)&1)<<2 -> the ds_read_b64_tr_b16 (4 rows x 4 chunks per
+//                                    32-lane half) is conflict-free; the 16 reads of a tile
+//                                    are two per-lane bases + immediates
+// (checked with tools/lds_bank_model.py).  The DMA writes LDS linearly, so the inverse
+// map goes on the source address.
+AACLIP_DEV int xk(int row) { return (row >> 1) & 7; }
+AACLIP_DEV int xv(int row) { return ((row >> 1) & 1) << 2; }
+
+// LOG2Q = true: q arrives multiplied by head_dim^-1/2 * log2(e) (aaclip_block folds the
+// factor into the QKV GEMM epilogue, one rounding), so scores are already in log2 units and
+// the running maximum is subtracted INSIDE the S^T MFMA chain by starting its accumulator at
+// -max: the softmax numerator is one v_exp_f32 per element.  LOG2Q = false: q carries
+// head_dim^-1/2 only (the plain aaclip_attention contract) and the factor is applied here.
+template <typename T, bool LOG2Q>
+__global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
+                                                        int causal) {
   typedef typename Elem<T>::vec8 vec8;
   typedef typename Elem<T>::vec4 vec4;
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) char smem[32768];  // 2 stages x (K 8K + V 8K)
+  constexpr float LOG2E = 1.4426950408889634f;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int D = H * 64;
@@ -39,53 +58,60 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
 
   vec8 qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
+  }
 
-  // DMA source (row, chunk) of the two wave-instructions this wave issues per tile
-  int srow[2], scol[2];
+  // DMA: this wave fills rows [16*wave, 16*wave+16) of the K and of the V tile (2 x 1 KiB each)
+  const T* ksrc[2];
+  const T* vsrc[2];
+  int drow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int row, chunk;
-    tile_src((wave * 2 + j) * 64 + lane, row, chunk);
-    srow[j] = row;
-    scol[j] = chunk * 8;
+    const int pslot = (wave * 2 + j) * 64 + lane;  // linear 16-byte slot
+    const int row = pslot >> 3, sl = pslot & 7;
+    drow[j] = row;
+    ksrc[j] = base + (long)row * ld + D + (sl ^ xk(row)) * 8;
+    vsrc[j] = base + (long)row * ld + 2 * D + (sl ^ xv(row)) * 8;
   }
-  int koff[2][4];
+  // K operand reads: row = sub*32 + r, chunk = 2*ks + h  ->  4 per-lane bases, sub adds 4096
+  int koff[4];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[sub][ks] = tile_off(sub * 32 + r, 2 * ks + h);
-  // transposed-read addresses: lane group g = lane>>4, i = lane&15 = 4*qq + pp
-  int voff[2][2][2][2];
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ xk(r)) << 4);
+  // V transposed reads: lane group g = lane>>4, i = lane&15 = 4*qq + pp; block rows key0+qq,
+  // key0 = sub*32 + 16*s2 + 8*t + 4*(g>>1); columns db*32 + (g&1)*16 + 4*pp
+  int voff[2];
   {
     const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+    const int row = 4 * (g >> 1) + qq;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            int key = sub * 32 + 16 * s2 + 8 * t + 4 * (g >> 1) + qq;
-            int col = db * 32 + (g & 1) * 16 + 4 * pp;
-            voff[sub][s2][t][db] = 8192 + tile_off(key, col >> 3) + (col & 7) * 2;
-          }
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
+      voff[db] = 8192 + row * 128 + ((chunk ^ xv(row)) << 4) + (pp & 1) * 8;
+    }
   }
 
   int last_q = qt * 128 + 127;
   if (last_q > L - 1) last_q = L - 1;
   const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
 
-  auto stage = [&](int s, int kt) {
-    char* dst = smem + s * 16384 + wave * 2048;
+  auto stage = [&](int st, int kt) {
+    char* dst = smem + st * 16384 + wave * 2048;
+    const long step = (long)kt * 64 * ld;
+    if (kt * 64 + 64 <= L) {   // whole tile in range: no clamping
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int key = kt * 64 + srow[j];
-      key = key < L ? key : L - 1;
-      const T* src = base + (long)key * ld + scol[j];
-      glds16(src + D, dst + j * 1024);
-      glds16(src + 2 * D, dst + 8192 + j * 1024);
+      for (int j = 0; j < 2; ++j) {
+        glds16(ksrc[j] + step, dst + j * 1024);
+        glds16(vsrc[j] + step, dst + 8192 + j * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int over = kt * 64 + drow[j] - (L - 1);
+        over = over > 0 ? over : 0;   // rows past the end re-read row L-1 (masked later)
+        glds16(ksrc[j] + step - (long)over * ld, dst + j * 1024);
+        glds16(vsrc[j] + step - (long)over * ld, dst + 8192 + j * 1024);
+      }
     }
   };
 
@@ -94,25 +120,23 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-  float m = -INFINITY, l = 0.f;
+  float m2 = 0.f, l = 0.f;   // running row max in log2 units (valid after the first tile), row sum
 
-  stage(0, 0);
-  wait_vm0();
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    const char* sb = smem + cur * 16384;
-
+  auto tile = [&](const char* sb, int kt) {
+    // S'^T = K . Q^T - m2 : the accumulator starts at -m2 (the query is on the lane)
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+      for (int e = 0; e < 16; ++e) s[sub][e] = LOG2Q ? -m2 : 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        vec8 a = *(const vec8*)(sb + koff[sub][ks]);
+        vec8 a = *(const vec8*)(sb + koff[ks] + sub * 4096);
         s[sub] = Elem<T>::mma32(a, qf[ks], s[sub]);
+      }
+      if (!LOG2Q) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = fmaf(s[sub][e], LOG2E, -m2);
       }
     }
     const int k0 = kt * 64;
@@ -133,24 +157,34 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
 #pragma unroll
       for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s[sub][e]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
-    const float alpha = __expf(m - mn);
+    // mt is the tile maximum relative to the running maximum.  Only when some row of this
+    // wave raises its maximum (always in the first tile) are scores, O and l re-based.
+    const bool first = kt == 0;
+    if (first || __any(mt > 0.f)) {
+      const float delta = first ? mt : fmaxf(mt, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m2 += delta;
+      l *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float pv = __expf(s[sub][e] - mn);
+        float pv = __builtin_amdgcn_exp2f(s[sub][e]);
         s[sub][e] = pv;
         rs += pv;
       }
     rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
-    m = mn;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+    l += rs;
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -161,16 +195,26 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
         for (int j = 0; j < 8; ++j) pf[j] = from_float<T>(s[sub][8 * s2 + j]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(sb + voff[sub][s2][0][db]));
-          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(sb + voff[sub][s2][1][db]));
-          typedef short i16x8 __attribute__((ext_vector_type(8)));
+          const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
           i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          vec8 vf = __builtin_bit_cast(vec8, both);
-          o[db] = Elem<T>::mma32(vf, pf, o[db]);
+          o[db] = Elem<T>::mma32(__builtin_bit_cast(vec8, both), pf, o[db]);
         }
       }
+  };
+
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {   // unrolled by two so the stage offsets are immediates
+    if (kt + 1 < nkt) stage(1, kt + 1);
+    tile(smem, kt);
+    wait_vm0();
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    if (kt + 2 < nkt) stage(0, kt + 2);
+    tile(smem + 16384, kt + 1);
     wait_vm0();
     __syncthreads();
   }
@@ -285,16 +329,20 @@ __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ q
   }
 }
 
-void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, hipStream_t s) {
+void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
+                      hipStream_t s) {
   if (dtype == AACLIP_F32) {
     dim3 g((L + 255) / 256, H, B);
     hipLaunchKernelGGL(attn32_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
   } else {
     dim3 g((L + 127) / 128, H, B);
-    if (dtype == AACLIP_F16)
-      hipLaunchKernelGGL(attn16_kernel<f16>, g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
-    else
-      hipLaunchKernelGGL(attn16_kernel<bf16>, g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+    if (dtype == AACLIP_F16) {
+      if (log2q) hipLaunchKernelGGL((attn16_kernel<f16, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16_kernel<f16, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    } else {
+      if (log2q) hipLaunchKernelGGL((attn16_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+    }
   }
 }
 

@@ -138,7 +138,7 @@ int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H,
   REQUIRE(qkv && ctx, "attention: null pointer");
   REQUIRE(B > 0 && L > 0 && H > 0, "attention: empty problem");
   REQUIRE(B <= 65535 && H <= 65535, "attention: grid limit");
-  launch_attention(dtype, qkv, ctx, B, L, H, causal, (hipStream_t)stream);
+  launch_attention(dtype, qkv, ctx, B, L, H, causal, 0, (hipStream_t)stream);
   return finish("attention");
 }
 
@@ -203,9 +203,11 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
   { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
   memset(&p, 0, sizeof(p));
   p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
-  p.ldc = 3 * D; p.scale_cols = D; p.scale = 0.125f;
+  // 16-bit path: fold log2(e) into the q scale (one rounding) so the attention kernel works in log2 units
+  const int log2q = dtype != AACLIP_F32;
+  p.ldc = 3 * D; p.scale_cols = D; p.scale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
   { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
-  { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, causal, s); }
+  { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, causal, log2q, s); }
   memset(&p, 0, sizeof(p));
   p.A = narrow; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
   { ProfScope ps(3, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }

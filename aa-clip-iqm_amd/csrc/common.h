@@ -104,4 +104,20 @@ AACLIP_DEV int xcd_remap(int id, int n) {
 
 // exact-erf GELU (nn.GELU default), reference model/model.py:84
 AACLIP_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for 16-bit outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// far below the 16-bit output rounding); the fp32 parity path keeps erff.
+AACLIP_DEV float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __expf(-z * z);
+  const float erf_abs = 1.0f - poly * e;          // erf(|x|/sqrt2)
+  const float half_x = 0.5f * x;
+  return fmaf(fabsf(half_x), erf_abs, half_x);     // 0.5x(1 + sign(x) erf|.|) = 0.5x + 0.5|x| erf|.|
+}
+
 AACLIP_DEV float leaky(float x) { return x >= 0.f ? x : 0.01f * x; }

@@ -27,7 +27,9 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
     if (col < p.scale_cols) v *= p.scale;
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
   } else if (EPI == EPI_BIAS_GELU) {
-    v = gelu_erf(v + p.bias[col]);
+    // 16-bit outputs: the A&S erf (error far below the output rounding), same in every 16-bit kernel so that
+    // results do not depend on which tile size a batch selects; fp32 keeps erff
+    v = sizeof(TOut) == 4 ? gelu_erf(v + p.bias[col]) : gelu_fast(v + p.bias[col]);
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
   } else if (EPI == EPI_BIAS_RESID) {
     float* x = (float*)p.out + (long)row * p.ldc + col;
@@ -248,8 +250,9 @@ static int g_gemm_variant = 0;  // 0 auto, 1 force the 128-tile kernel, 2 force 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
-  if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant == 2 || p.M >= 4096)) {
-    launch_gemm256(dtype, epi, p, s);
+  // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
+  if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {
+    launch_gemm256(dtype, epi, p, s, g_gemm_variant >= 3 ? g_gemm_variant - 2 : 0);  // 4, 5: timing ablations
     return;
   }
   const int tiles = ((p.M + 127) / 128) * (p.N / 128);

@@ -27,11 +27,13 @@ struct GemmParams {
 const char* gemm_check(int dtype, int epi, const GemmParams& p);
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s);
 bool gemm256_applicable(int dtype, const GemmParams& p);
-void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s);
+void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined);
 void set_gemm_variant(int v);
 
 // fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]
-void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, hipStream_t s);
+// log2q != 0: q is pre-multiplied by log2(e) as well (16-bit kernels only)
+void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
+                      hipStream_t s);
 
 // row ops (rowops.hip); D in {256, 768, 1024}
 const char* row_width_check(int D);

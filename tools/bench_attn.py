@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time the fused attention kernel at the tower's shape (B=64, L=1370, H=16, head 64)."""
+import argparse, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "aa-clip-iqm_amd"))
+import torch
+from aaclip_hip import _lib
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--L", type=int, default=1370)
+ap.add_argument("--H", type=int, default=16)
+ap.add_argument("--causal", type=int, default=0)
+a = ap.parse_args()
+lib = _lib.load()
+dev = torch.device("cuda:0")
+B, L, H = a.batch, a.L, a.H
+D = 64 * H
+qkv = torch.randn(B * L, 3 * D, device=dev)
+qkv[:, :D] *= 0.5
+qkv = qkv.half()
+ctx = torch.empty(B * L, D, device=dev, dtype=torch.float16)
+st = torch.cuda.current_stream().cuda_stream
+def run():
+    _lib.check(lib.aaclip_attention(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, a.causal, st))
+run(); torch.cuda.synchronize()
+fl = 4.0 * B * H * L * L * 64 * (0.5 if a.causal else 1.0)
+ts = []
+for r in range(a.rounds):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 5)
+ts.sort()
+print(f"attention B={B} L={L} H={H}: median {ts[len(ts)//2]:.3f} ms -> {fl/ts[len(ts)//2]/1e9:.0f} TF")

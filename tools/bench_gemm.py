@@ -12,6 +12,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="1,2")
 ap.add_argument("--dtype", default="f16")
+ap.add_argument("--only", default="")
 a = ap.parse_args()
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -20,7 +21,12 @@ tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
 M = a.batch * 1370
 shapes = [("qkv", _lib.EPI_BIAS, 3072, 1024), ("out_proj", _lib.EPI_BIAS_RESID, 1024, 1024),
           ("c_fc", _lib.EPI_BIAS_GELU, 4096, 1024), ("c_proj", _lib.EPI_BIAS_RESID, 1024, 4096),
-          ("adapter", _lib.EPI_ACT_F32, 1024, 1024), ("seg_proj", _lib.EPI_ACT_F32, 768, 1024)]
+          ("adapter", _lib.EPI_ACT_F32, 1024, 1024), ("seg_proj", _lib.EPI_ACT_F32, 768, 1024),
+          ("k4096_f32out", _lib.EPI_ACT_F32, 1024, 4096), ("n4096_f32out", _lib.EPI_ACT_F32, 4096, 1024)]
+if a.only:
+    shapes = [s for s in shapes if s[0] in a.only.split(",")]
+if any(v >= 4 for v in [int(v) for v in a.variants.split(",")]):
+    shapes = [s for s in shapes if s[1] == _lib.EPI_ACT_F32]   # timing ablations exist for the fp32-out epilogue only
 variants = [int(v) for v in a.variants.split(",")]
 st = torch.cuda.current_stream().cuda_stream
 res = {}
