@@ -234,6 +234,253 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
   }
 }
 
+// ---------------------------------------------------------------------------
+// Long-sequence variant (the visual tower, L = 1370): one wave owns TWO 32-row
+// query blocks (64 rows), a workgroup 256 rows, so every K/V fragment read from
+// LDS and every DMA'd byte feeds twice the MFMA work, and the two blocks give
+// the scheduler two independent softmax chains.  K/V tiles go through a 4-stage
+// ring (three tiles = 48 KiB in flight per workgroup, two workgroups per CU)
+// with counted vmcnt waits: the 2-stage kernel above was bound by DMA latency x
+// bytes in flight, not by MFMA or VALU.
+template <typename T, bool LOG2Q>
+__global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
+                                                          int causal) {
+  typedef typename Elem<T>::vec8 vec8;
+  typedef typename Elem<T>::vec4 vec4;
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) char smem[65536];  // 4 stages x (K 8K + V 8K)
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const T* base = qkv + (long)b * L * ld + head * 64;
+  const int q0 = qt * 256 + wave * 64;
+  const bool active = q0 < L;   // wave-uniform: idle waves only feed the ring and the barriers
+
+  vec8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int qrow = q0 + qb * 32 + r;
+    qrow = qrow < L ? qrow : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
+  }
+
+  const T* ksrc[2];
+  const T* vsrc[2];
+  int drow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pslot = (wave * 2 + j) * 64 + lane;
+    const int row = pslot >> 3, sl = pslot & 7;
+    drow[j] = row;
+    ksrc[j] = base + (long)row * ld + D + (sl ^ xk(row)) * 8;
+    vsrc[j] = base + (long)row * ld + 2 * D + (sl ^ xv(row)) * 8;
+  }
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ xk(r)) << 4);
+  int voff[2];
+  {
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+    const int row = 4 * (g >> 1) + qq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
+      voff[db] = 8192 + row * 128 + ((chunk ^ xv(row)) << 4) + (pp & 1) * 8;
+    }
+  }
+
+  int last_q = qt * 256 + 255;
+  if (last_q > L - 1) last_q = L - 1;
+  const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
+
+  auto stage = [&](int st, int kt) {
+    char* dst = smem + st * 16384 + wave * 2048;
+    const long step = (long)kt * 64 * ld;
+    if (kt * 64 + 64 <= L) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        glds16(ksrc[j] + step, dst + j * 1024);
+        glds16(vsrc[j] + step, dst + 8192 + j * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int over = kt * 64 + drow[j] - (L - 1);
+        over = over > 0 ? over : 0;
+        glds16(ksrc[j] + step - (long)over * ld, dst + j * 1024);
+        glds16(vsrc[j] + step - (long)over * ld, dst + 8192 + j * 1024);
+      }
+    }
+  };
+
+  f32x16 o[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][db][e] = 0.f;
+  float m2[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+
+  auto tile = [&](const char* sb, int kt) {
+    f32x16 s[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[qb][sub][e] = LOG2Q ? -m2[qb] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      vec8 k0f = *(const vec8*)(sb + koff[ks]);
+      vec8 k1f = *(const vec8*)(sb + koff[ks] + 4096);
+      s[0][0] = Elem<T>::mma32(k0f, qf[0][ks], s[0][0]);
+      s[1][0] = Elem<T>::mma32(k0f, qf[1][ks], s[1][0]);
+      s[0][1] = Elem<T>::mma32(k1f, qf[0][ks], s[0][1]);
+      s[1][1] = Elem<T>::mma32(k1f, qf[1][ks], s[1][1]);
+    }
+    if (!LOG2Q) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[qb][sub][e] = fmaf(s[qb][sub][e], LOG2E, -m2[qb]);
+    }
+    const int k0 = kt * 64;
+    const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));
+    if (need_mask) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            int key = k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            bool dead = (key >= L) || (causal && key > q0 + qb * 32 + r);
+            s[qb][sub][e] = dead ? -INFINITY : s[qb][sub][e];
+          }
+    }
+    float mt[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float a = s[qb][0][0], c = s[qb][1][0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) {
+        a = fmaxf(a, s[qb][0][e]);
+        c = fmaxf(c, s[qb][1][e]);
+      }
+      a = fmaxf(a, c);
+      mt[qb] = fmaxf(a, __shfl_xor(a, 32, 64));
+    }
+    const bool first = kt == 0;
+    if (first || __any(fmaxf(mt[0], mt[1]) > 0.f)) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m2[qb] += delta;
+        l[qb] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[qb][sub][e] -= delta;
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float ra = 0.f, rb = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pa = __builtin_amdgcn_exp2f(s[qb][0][e]);
+        float pb = __builtin_amdgcn_exp2f(s[qb][1][e]);
+        s[qb][0][e] = pa;
+        s[qb][1][e] = pb;
+        ra += pa;
+        rb += pb;
+      }
+      ra += rb;
+      l[qb] += ra + __shfl_xor(ra, 32, 64);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        vec8 vf[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
+          i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          vf[db] = __builtin_bit_cast(vec8, both);
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          vec8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = from_float<T>(s[qb][sub][8 * s2 + j]);
+          o[qb][0] = Elem<T>::mma32(vf[0], pf, o[qb][0]);
+          o[qb][1] = Elem<T>::mma32(vf[1], pf, o[qb][1]);
+        }
+      }
+  };
+
+  // ring prologue: up to three tiles in flight
+  stage(0, 0);
+  if (nkt > 1) stage(1, 1);
+  if (nkt > 2) stage(2, 2);
+#define RING_STEP(i)                                                      \
+  {                                                                       \
+    const int t = kt + (i);                                               \
+    if (t >= nkt) break;                                                  \
+    const int younger = nkt - 1 - t;                                      \
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    \
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    __builtin_amdgcn_s_barrier();                                         \
+    if (t + 3 < nkt) stage(((i) + 3) & 3, t + 3);                         \
+    if (active) tile(smem + (i) * 16384, t);                              \
+  }
+  for (int kt = 0; kt < nkt; kt += 4) {
+    RING_STEP(0)
+    RING_STEP(1)
+    RING_STEP(2)
+    RING_STEP(3)
+  }
+#undef RING_STEP
+
+  if (active) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qi = q0 + qb * 32 + r;
+      if (qi < L) {
+        const float inv = 1.0f / l[qb];
+        T* dst = ctx + ((long)b * L + qi) * D + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            vec4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = from_float<T>(o[qb][db][4 * gi + j] * inv);
+            *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = v;
+          }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ fp32 path
 __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L,
                                                      int H, int causal) {
@@ -329,11 +576,23 @@ __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ q
   }
 }
 
+static int g_attn_variant = 0;  // 1 = always the 2-stage 128-row kernel (A/B measurements)
+void set_attn_variant(int v) { g_attn_variant = v; }
+
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
                       hipStream_t s) {
   if (dtype == AACLIP_F32) {
     dim3 g((L + 255) / 256, H, B);
     hipLaunchKernelGGL(attn32_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
+  } else if (L >= 512 && g_attn_variant != 1) {
+    dim3 g((L + 255) / 256, H, B);
+    if (dtype == AACLIP_F16) {
+      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<f16, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16x2_kernel<f16, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    } else {
+      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16x2_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+    }
   } else {
     dim3 g((L + 127) / 128, H, B);
     if (dtype == AACLIP_F16) {

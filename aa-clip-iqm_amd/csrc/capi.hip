@@ -89,7 +89,8 @@ int aaclip_profile_end(float* ms, int* tags, int max_n) {
 }
 
 int aaclip_set_gemm_variant(int v) {
-  set_gemm_variant(v);
+  set_gemm_variant(v & 0xFF);
+  set_attn_variant((v >> 8) & 0xFF);   // bits 8..15: attention kernel selection
   return 0;
 }
 

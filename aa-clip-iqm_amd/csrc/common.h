@@ -104,20 +104,34 @@ AACLIP_DEV int xcd_remap(int id, int n) {
 
 // exact-erf GELU (nn.GELU default), reference model/model.py:84
 AACLIP_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// GELU for 16-bit outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
-// far below the 16-bit output rounding); the fp32 parity path keeps erff.
-AACLIP_DEV float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __expf(-z * z);
-  const float erf_abs = 1.0f - poly * e;          // erf(|x|/sqrt2)
-  const float half_x = 0.5f * x;
-  return fmaf(fabsf(half_x), erf_abs, half_x);     // 0.5x(1 + sign(x) erf|.|) = 0.5x + 0.5|x| erf|.|
+// GELU for 16-bit outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// 16-bit output rounding); the fp32 parity path keeps erff.  Two values at once on packed-f32
+// VALU (v_pk_fma_f32 / v_pk_mul_f32): half the full-rate instructions per element in the GEMM
+// epilogues, where no MFMA runs beside it.  Every 16-bit kernel uses this one routine so results
+// do not depend on which kernel a batch size selects.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+AACLIP_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+AACLIP_DEV f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 d = fma2(z, (f32x2){0.3275911f, 0.3275911f}, one);
+  f32x2 t;
+  t[0] = __builtin_amdgcn_rcpf(d[0]);
+  t[1] = __builtin_amdgcn_rcpf(d[1]);
+  f32x2 poly = fma2(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+  poly = fma2(poly, t, (f32x2){1.421413741f, 1.421413741f});
+  poly = fma2(poly, t, (f32x2){-0.284496736f, -0.284496736f});
+  poly = fma2(poly, t, (f32x2){0.254829592f, 0.254829592f});
+  poly = poly * t;
+  const f32x2 zz = (z * z) * -1.4426950408889634f;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(zz[0]);
+  e[1] = __builtin_amdgcn_exp2f(zz[1]);
+  const f32x2 erf_abs = fma2(-poly, e, one);          // erf(|x|/sqrt2)
+  const f32x2 hx = x * 0.5f;
+  return fma2(ax * 0.5f, erf_abs, hx);                // 0.5x(1 + sign(x) erf|.|) = 0.5x + 0.5|x| erf|.|
 }
+AACLIP_DEV float gelu_fast(float x) { return gelu_fast2((f32x2){x, x})[0]; }
 
 AACLIP_DEV float leaky(float x) { return x >= 0.f ? x : 0.01f * x; }

@@ -252,7 +252,12 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {
-    launch_gemm256(dtype, epi, p, s, g_gemm_variant >= 3 ? g_gemm_variant - 2 : 0);  // 4, 5: timing ablations
+    if (g_gemm_variant == 0 || g_gemm_variant == 6) {   // default: 16x16x32 MFMA shape
+      launch_gemm256t(dtype, epi, p, s);
+      return;
+    }
+    // 0/3: DMA issued between the MFMAs (default); 2: DMA at the phase start; 4, 5: timing ablations
+    launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : (g_gemm_variant >= 3 ? g_gemm_variant - 2 : 1));
     return;
   }
   const int tiles = ((p.M + 127) / 128) * (p.N / 128);

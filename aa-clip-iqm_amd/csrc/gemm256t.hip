@@ -1,0 +1,272 @@
+// 256x256x64 NT GEMM on v_mfma_f32_16x16x32 (gfx950).
+//
+// Same workgroup geometry, phase schedule and DMA placement as gemm16_256s_kernel
+// (gemm256.hip): 8 waves = 2 (M) x 4 (N), 128x64 of C per wave, four output
+// quadrants per K tile, the two DMA instructions of a phase issued between its
+// MFMAs, counted vmcnt waits.  The differences:
+//   * MFMA shape 16x16x32 instead of 32x32x16.  Cycles per FLOP are equal, but in
+//     an MFMA-dense loop on random data the chip holds a higher clock on this
+//     shape (MI355X_MICROARCH.md, DVFS give-back item 7), so it is faster by wall.
+//   * LDS tile swizzle slot ^= (row_pair & 15), which is bank-conflict-free for
+//     the 16x16x32 operand read (lane -> row l&15, chunk 4*ks + (l>>4)) as well
+//     as for the 32x32x16 one (tools/lds_bank_model.py).
+// Operand roles are swapped as in the other kernel (W rows = MFMA A operand), so a
+// lane holds output column m = lane&15 and rows n = 4*(lane>>4) + j of each 16x16 tile.
+#include "common.h"
+#include "kernels.h"
+
+namespace aaclip {
+
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+  static AACLIP_DEV f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma16<bf16> {
+  static AACLIP_DEV f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+AACLIP_DEV int tile_off_id(int row, int chunk) {
+  const int rp = row >> 1;
+  return rp * 256 + (((((row & 1) << 3) | chunk) ^ (rp & 15)) << 4);
+}
+AACLIP_DEV void tile_src_id(int p, int& row, int& chunk) {
+  const int rp = p >> 4;
+  const int s = (p & 15) ^ (rp & 15);
+  row = rp * 2 + (s >> 3);
+  chunk = s & 7;
+}
+
+// acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
+template <typename T, int EPI>
+AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane) {
+  typedef typename Elem<T>::vec4 vec4;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m_base = tm * 256 + wr * 128, n_base = tn * 256 + wc * 64;
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    __syncthreads();  // every wave is done reading the operand tiles
+    char* st = smem + wave * 16384;  // this wave's 128 x 64 tile of T: rows of 128 B, 16-B chunk ^= (m & 7)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int nl = ni * 16 + 4 * q4;   // local column of this lane's 4 values
+      const f32x4 bv = *(const f32x4*)(p.bias + n_base + nl);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        vec4 o;
+        if (EPI == EPI_BIAS_GELU) {
+          f32x2 g0 = {acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]};
+          f32x2 g1 = {acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]};
+          g0 = gelu_fast2(g0);
+          g1 = gelu_fast2(g1);
+          o[0] = from_float<T>(g0[0]); o[1] = from_float<T>(g0[1]);
+          o[2] = from_float<T>(g1[0]); o[3] = from_float<T>(g1[1]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[mi][ni][j] + bv[j];
+            if (n_base + nl + j < p.scale_cols) v *= p.scale;
+            o[j] = from_float<T>(v);
+          }
+        }
+        const int m = mi * 16 + c16;
+        *(vec4*)(st + m * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int m = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
+      const int row = m_base + m;
+      if (row < p.M) *(u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8) = v;
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int row = m_base + mi * 16 + c16;
+      if (row < p.M) {
+        long orow = row;
+        const float* posr = nullptr;
+        if (EPI == EPI_PATCH) {
+          const int b = row / p.P, pi = row - b * p.P;
+          orow = (long)b * p.L + 1 + pi;
+          posr = p.pos + (long)(1 + pi) * p.N;
+        }
+        float* op = (float*)p.out + orow * p.ldc;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n0 = n_base + ni * 16 + 4 * q4;
+          f32x4 v = acc[mi][ni];
+          if (EPI == EPI_BIAS_RESID) {
+            const f32x4 bv = *(const f32x4*)(p.bias + n0);
+            const f32x4 x = *(const f32x4*)(op + n0);
+            v = x + (v + bv);
+          } else if (EPI == EPI_ACT_F32) {
+            if (p.bias) v = v + *(const f32x4*)(p.bias + n0);
+            if (p.act == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = leaky(v[j]);
+            }
+          } else if (EPI == EPI_PATCH) {
+            v = v + *(const f32x4*)(posr + n0);
+          }
+          *(f32x4*)(op + n0) = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm16_256t_kernel(GemmParams p, int PN, int patches_n, int total_patches) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[131072];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = (p.M + 255) >> 8;
+  int tm, tn;
+  {
+    const int P = 8 * PN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gp = (j / P) * 8 + xcd, local = j % P;
+    if (gp >= total_patches) return;
+    const int pm = gp / patches_n, pn = gp - pm * patches_n;
+    tm = pm * 8 + local / PN;
+    tn = pn * PN + local % PN;
+    if (tm >= tiles_m) return;
+  }
+  // DMA: half-operand `sub` of the M side = LDS row groups {0..7,16..23}+8*sub (rows of the
+  // waves' a-sub), of the N side = groups {0..3,8..11,16..19,24..27}+4*sub; 2 x 1 KiB per wave.
+  int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      const int ga = (idx & 7) + (idx >> 3) * 16 + sub * 8;
+      const int gw = (idx & 3) + (idx >> 2) * 8 + sub * 4;
+      int row, chunk;
+      tile_src_id(ga * 64 + lane, row, chunk);
+      int ar = tm * 256 + row;
+      ar = ar < p.M ? ar : p.M - 1;
+      srcA[sub][j] = (ar - tm * 256) * (int)p.lda + chunk * 8;
+      dstA[sub][j] = ga * 1024;
+      tile_src_id(gw * 64 + lane, row, chunk);
+      srcW[sub][j] = row * p.K + chunk * 8;
+      dstW[sub][j] = 32768 + gw * 1024;
+    }
+  const T* baseA = (const T*)p.A + (long)tm * 256 * p.lda;
+  const T* baseW = (const T*)p.W + (long)tn * 256 * p.K;
+  // fragment reads: row = base + 16*t + (lane&15), chunk = 4*ks + (lane>>4).  Tiles 32 rows
+  // apart differ by 4096 bytes; the odd 16-row tile flips the 128-byte half, so it has its own base.
+  int offM[2][2], offN[2][2];   // [ks][tile parity]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      offM[ks][par] = tile_off_id(wr * 128 + par * 16 + c16, 4 * ks + q4);
+      offN[ks][par] = 32768 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 6;
+#define G1(base, src, dst, st, kt) glds16(base + src + (kt) * 64, smem + (st) * 65536 + dst);
+#define GA(sub, st, kt) { G1(baseA, srcA[sub][0], dstA[sub][0], st, kt) G1(baseA, srcA[sub][1], dstA[sub][1], st, kt) }
+#define GW(sub, st, kt) { G1(baseW, srcW[sub][0], dstW[sub][0], st, kt) G1(baseW, srcW[sub][1], dstW[sub][1], st, kt) }
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define BAR __builtin_amdgcn_s_barrier();
+#define PINB __builtin_amdgcn_sched_barrier(0);
+// M-side fragments of a-sub `a`: 16-row tiles 4a..4a+3 -> fm[t][ks]; N-side of b-sub `b`: tiles 2b, 2b+1 -> fn[t][ks]
+#define LD_M(sb, a)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) \
+      fm[t][ks] = *(const vec8*)((sb) + offM[ks][t & 1] + ((a) * 2 + (t >> 1)) * 4096);
+#define LD_N(sb, b)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 2; ++t) \
+      fn[t][ks] = *(const vec8*)((sb) + offN[ks][t] + (b) * 4096);
+#define MM(a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(fn[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+// 16 MFMAs of one quadrant, the phase's two DMA instructions after the 4th and the 10th
+#define QUAD(a, b, I0, I1)                                                   \
+  {                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                           \
+    MM(a, b, 0, 0, 0) MM(a, b, 0, 1, 0) MM(a, b, 1, 0, 0) MM(a, b, 1, 1, 0)  \
+    PINB I0 PINB                                                             \
+    MM(a, b, 2, 0, 0) MM(a, b, 2, 1, 0) MM(a, b, 3, 0, 0) MM(a, b, 3, 1, 0)  \
+    MM(a, b, 0, 0, 1) MM(a, b, 0, 1, 1)                                      \
+    PINB I1 PINB                                                             \
+    MM(a, b, 1, 0, 1) MM(a, b, 1, 1, 1) MM(a, b, 2, 0, 1) MM(a, b, 2, 1, 1)  \
+    MM(a, b, 3, 0, 1) MM(a, b, 3, 1, 1)                                      \
+    __builtin_amdgcn_s_setprio(0);                                           \
+  }
+
+  GA(0, 0, 0) GW(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)   // prologue: tile 0 in consumption order
+
+  vec8 fm[4][2], fn[2][2];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more = kt + 1 < nk;
+    const char* sb = smem + cur * 65536;
+    // P0 (A0,B0): needs A0,B0(kt); younger in flight: B1, A1
+    WAIT_VM(4);
+    BAR
+    LD_N(sb, 0)
+    LD_M(sb, 0)
+    QUAD(0, 0, if (more) G1(baseA, srcA[0][0], dstA[0][0], nxt, kt + 1), if (more) G1(baseA, srcA[0][1], dstA[0][1], nxt, kt + 1))
+    // P1 (A0,B1): needs B1(kt); younger: A1(kt) [+ A0(kt+1)]
+    if (more) WAIT_VM(4); else WAIT_VM(2);
+    BAR
+    LD_N(sb, 1)
+    QUAD(0, 1, if (more) G1(baseW, srcW[0][0], dstW[0][0], nxt, kt + 1), if (more) G1(baseW, srcW[0][1], dstW[0][1], nxt, kt + 1))
+    // P2 (A1,B1): needs A1(kt); younger: [A0(kt+1), B0(kt+1)]
+    if (more) WAIT_VM(4); else WAIT_VM(0);
+    BAR
+    LD_M(sb, 1)
+    QUAD(1, 1, if (more) G1(baseW, srcW[1][0], dstW[1][0], nxt, kt + 1), if (more) G1(baseW, srcW[1][1], dstW[1][1], nxt, kt + 1))
+    // P3 (A1,B0): B0(kt) landed before P0
+    LD_N(sb, 0)
+    QUAD(1, 0, if (more) G1(baseA, srcA[1][0], dstA[1][0], nxt, kt + 1), if (more) G1(baseA, srcA[1][1], dstA[1][1], nxt, kt + 1))
+  }
+#undef G1
+#undef GA
+#undef GW
+#undef WAIT_VM
+#undef BAR
+#undef PINB
+#undef LD_M
+#undef LD_N
+#undef MM
+#undef QUAD
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+}
+
+template <typename T>
+static void launch_t(int epi, const GemmParams& p, hipStream_t s) {
+  const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
+  const int PN = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0) ? 3 : (tiles_n % 2 == 0) ? 2 : 1;
+  const int patches_n = tiles_n / PN, patches_m = (tiles_m + 7) / 8;
+  const int total = patches_n * patches_m;
+  const int grid = ((total + 7) / 8) * 8 * 8 * PN;
+  dim3 g(grid), b(512);
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_RESID>), g, b, 0, s, p, PN, patches_n, total); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_ACT_F32>), g, b, 0, s, p, PN, patches_n, total); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_PATCH>), g, b, 0, s, p, PN, patches_n, total); break;
+  }
+}
+
+void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+  if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s);
+  else launch_t<bf16>(epi, p, s);
+}
+
+}  // namespace aaclip

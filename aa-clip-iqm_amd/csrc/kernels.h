@@ -28,7 +28,9 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p);
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s);
 bool gemm256_applicable(int dtype, const GemmParams& p);
 void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined);
+void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s);
 void set_gemm_variant(int v);
+void set_attn_variant(int v);
 
 // fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]
 // log2q != 0: q is pre-multiplied by log2(e) as well (16-bit kernels only)

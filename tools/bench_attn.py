@@ -11,13 +11,16 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--L", type=int, default=1370)
 ap.add_argument("--H", type=int, default=16)
 ap.add_argument("--causal", type=int, default=0)
+ap.add_argument("--variant", type=int, default=0, help="1 = force the 128-row kernel")
+ap.add_argument("--scale", type=float, default=0.5)
 a = ap.parse_args()
 lib = _lib.load()
+lib.aaclip_set_gemm_variant(a.variant << 8)
 dev = torch.device("cuda:0")
 B, L, H = a.batch, a.L, a.H
 D = 64 * H
 qkv = torch.randn(B * L, 3 * D, device=dev)
-qkv[:, :D] *= 0.5
+qkv[:, :D] *= a.scale
 qkv = qkv.half()
 ctx = torch.empty(B * L, D, device=dev, dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
