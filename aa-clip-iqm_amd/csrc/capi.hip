@@ -94,6 +94,11 @@ int aaclip_set_gemm_variant(int v) {
   return 0;
 }
 
+int aaclip_debug_gemm_stamps(double* out3, int nwaves) {
+  read_gemm_stamps(out3, nwaves);
+  return 0;
+}
+
 int aaclip_version(void) { return AACLIP_ABI_VERSION; }
 const char* aaclip_last_error(void) { return g_err; }
 

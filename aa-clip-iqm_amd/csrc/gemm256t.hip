@@ -247,14 +247,615 @@ __global__ __launch_bounds__(512, 2) void gemm16_256t_kernel(GemmParams p, int P
   epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Overlapped variant: the LDS fragment reads of the NEXT quadrant are issued
+// inside the current MFMA cluster, each one right after the last MFMA that
+// consumes the register it overwrites (one register set per operand side).  The
+// 224 KiB of LDS reads per K tile (896 LDS cycles per CU) then run under the
+// matrix pipe instead of in front of it.  Consequence for the DMA ring: a
+// half-operand must be confirmed landed one phase before the phase that
+// multiplies it, so the issue schedule is shifted one phase earlier:
+//   issue  A0(t+1)@(t-1,P3)  B0(t+1)@(t,P0)  B1(t+1)@(t,P1)  A1(t+1)@(t,P2)
+//   read   A0,B0(t+1) during (t,P3)   B1(t+1) during (t+1,P0)   A1(t+1) during (t+1,P1)
+// All steady-state waits are vmcnt(4): two half-operands stay in flight.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm16_256u_kernel(GemmParams p, int PN, int patches_n, int total_patches) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[131072];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = (p.M + 255) >> 8;
+  int tm, tn;
+  {
+    const int P = 8 * PN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gp = (j / P) * 8 + xcd, local = j % P;
+    if (gp >= total_patches) return;
+    const int pm = gp / patches_n, pn = gp - pm * patches_n;
+    tm = pm * 8 + local / PN;
+    tn = pn * PN + local % PN;
+    if (tm >= tiles_m) return;
+  }
+  int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      const int ga = (idx & 7) + (idx >> 3) * 16 + sub * 8;
+      const int gw = (idx & 3) + (idx >> 2) * 8 + sub * 4;
+      int row, chunk;
+      tile_src_id(ga * 64 + lane, row, chunk);
+      int ar = tm * 256 + row;
+      ar = ar < p.M ? ar : p.M - 1;
+      srcA[sub][j] = (ar - tm * 256) * (int)p.lda + chunk * 8;
+      dstA[sub][j] = ga * 1024;
+      tile_src_id(gw * 64 + lane, row, chunk);
+      srcW[sub][j] = row * p.K + chunk * 8;
+      dstW[sub][j] = 32768 + gw * 1024;
+    }
+  const T* baseA = (const T*)p.A + (long)tm * 256 * p.lda;
+  const T* baseW = (const T*)p.W + (long)tn * 256 * p.K;
+  int offM[2][2], offN[2][2];   // [ks][tile parity]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      offM[ks][par] = tile_off_id(wr * 128 + par * 16 + c16, 4 * ks + q4);
+      offN[ks][par] = 32768 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 6;
+#define G1(base, src, dst, st, kt) glds16(base + src + (kt) * 64, smem + (st) * 65536 + dst);
+#define GA(sub, st, kt) { G1(baseA, srcA[sub][0], dstA[sub][0], st, kt) G1(baseA, srcA[sub][1], dstA[sub][1], st, kt) }
+#define GW(sub, st, kt) { G1(baseW, srcW[sub][0], dstW[sub][0], st, kt) G1(baseW, srcW[sub][1], dstW[sub][1], st, kt) }
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define BAR __builtin_amdgcn_s_barrier();
+#define PINB __builtin_amdgcn_sched_barrier(0);
+#define RM(sb, a, t, ks) fm[t][ks] = *(const vec8*)((sb) + offM[ks][(t) & 1] + ((a) * 2 + ((t) >> 1)) * 4096);
+#define RN(sb, b, u, ks) fn[u][ks] = *(const vec8*)((sb) + offN[ks][u] + (b) * 4096);
+#define MM(a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(fn[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+// one pair of MFMAs (both n tiles of m tile t, k-step ks), then whatever rides behind it
+#define SLOT(a, b, ks, t, X) MM(a, b, t, 0, ks) MM(a, b, t, 1, ks) PINB X PINB
+// cluster that keeps fm and replaces fn by b-sub nb of stage sn (reads after the last use of each k-step)
+#define CL_NEWN(a, b, sn, nb, D0, D1)                                                    \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    SLOT(a, b, 0, 0, ) SLOT(a, b, 0, 1, D0) SLOT(a, b, 0, 2, )                           \
+    SLOT(a, b, 0, 3, RN(sn, nb, 0, 0) RN(sn, nb, 1, 0))                                  \
+    SLOT(a, b, 1, 0, ) SLOT(a, b, 1, 1, D1) SLOT(a, b, 1, 2, )                           \
+    SLOT(a, b, 1, 3, RN(sn, nb, 0, 1) RN(sn, nb, 1, 1))                                  \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+// cluster that keeps fn and replaces fm by a-sub na of stage sn (each fragment right after its two MFMAs)
+#define CL_NEWM(a, b, sn, na, D0, D1)                                                    \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    SLOT(a, b, 0, 0, RM(sn, na, 0, 0)) SLOT(a, b, 0, 1, RM(sn, na, 1, 0) D0)             \
+    SLOT(a, b, 0, 2, RM(sn, na, 2, 0)) SLOT(a, b, 0, 3, RM(sn, na, 3, 0))                \
+    SLOT(a, b, 1, 0, RM(sn, na, 0, 1)) SLOT(a, b, 1, 1, RM(sn, na, 1, 1) D1)             \
+    SLOT(a, b, 1, 2, RM(sn, na, 2, 1)) SLOT(a, b, 1, 3, RM(sn, na, 3, 1))                \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+// cluster that replaces both (transition to the next K tile)
+#define CL_NEWMN(a, b, sn, na, nb, D0, D1)                                               \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    SLOT(a, b, 0, 0, RM(sn, na, 0, 0)) SLOT(a, b, 0, 1, RM(sn, na, 1, 0) D0)             \
+    SLOT(a, b, 0, 2, RM(sn, na, 2, 0))                                                   \
+    SLOT(a, b, 0, 3, RM(sn, na, 3, 0) RN(sn, nb, 0, 0) RN(sn, nb, 1, 0))                 \
+    SLOT(a, b, 1, 0, RM(sn, na, 0, 1)) SLOT(a, b, 1, 1, RM(sn, na, 1, 1) D1)             \
+    SLOT(a, b, 1, 2, RM(sn, na, 2, 1))                                                   \
+    SLOT(a, b, 1, 3, RM(sn, na, 3, 1) RN(sn, nb, 0, 1) RN(sn, nb, 1, 1))                 \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+#define CL_LAST(a, b)                                                                    \
+  {                                                                                      \
+    SLOT(a, b, 0, 0, ) SLOT(a, b, 0, 1, ) SLOT(a, b, 0, 2, ) SLOT(a, b, 0, 3, )          \
+    SLOT(a, b, 1, 0, ) SLOT(a, b, 1, 1, ) SLOT(a, b, 1, 2, ) SLOT(a, b, 1, 3, )          \
+  }
+
+  // prologue: tile 0 in consumption order plus A0 of tile 1; first fragments
+  GA(0, 0, 0) GW(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
+  if (nk > 1) GA(0, 1, 1)
+  vec8 fm[4][2], fn[2][2];
+  if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
+  BAR
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) RM(smem, 0, t, ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) RN(smem, 0, u, ks)
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    const char* sb = smem + cur * 65536;
+    const char* sn = smem + nxt * 65536;
+    // P0 (A0,B0): fn <- B1(kt).  confirm B1(kt); younger: A1(kt) [, A0(kt+1)]
+    if (more1) WAIT_VM(4); else WAIT_VM(2);
+    BAR
+    CL_NEWN(0, 0, sb, 1, if (more1) G1(baseW, srcW[0][0], dstW[0][0], nxt, kt + 1), if (more1) G1(baseW, srcW[0][1], dstW[0][1], nxt, kt + 1))
+    // P1 (A0,B1): fm <- A1(kt).  confirm A1(kt); younger: [A0(kt+1), B0(kt+1)]
+    if (more1) WAIT_VM(4); else WAIT_VM(0);
+    BAR
+    CL_NEWM(0, 1, sb, 1, if (more1) G1(baseW, srcW[1][0], dstW[1][0], nxt, kt + 1), if (more1) G1(baseW, srcW[1][1], dstW[1][1], nxt, kt + 1))
+    // P2 (A1,B1): fn <- B0(kt) again
+    CL_NEWN(1, 1, sb, 0, if (more1) G1(baseA, srcA[1][0], dstA[1][0], nxt, kt + 1), if (more1) G1(baseA, srcA[1][1], dstA[1][1], nxt, kt + 1))
+    // P3 (A1,B0): fm,fn <- A0,B0(kt+1).  confirm them; younger: B1(kt+1), A1(kt+1)
+    if (more1) {
+      WAIT_VM(4);
+      BAR
+      CL_NEWMN(1, 0, sn, 0, 0, if (more2) G1(baseA, srcA[0][0], dstA[0][0], cur, kt + 2), if (more2) G1(baseA, srcA[0][1], dstA[0][1], cur, kt + 2))
+    } else {
+      CL_LAST(1, 0)
+    }
+  }
+#undef G1
+#undef GA
+#undef GW
+#undef WAIT_VM
+#undef BAR
+#undef PINB
+#undef RM
+#undef RN
+#undef MM
+#undef SLOT
+#undef CL_NEWN
+#undef CL_NEWM
+#undef CL_NEWMN
+#undef CL_LAST
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Staggered variant.  Every phase is split into a LOAD segment (counted DMA wait,
+// LDS fragment reads, optionally one DMA issue) and a COMPUTE segment (16 MFMAs with
+// the remaining DMA issue between them), each closed by s_barrier, and waves 4-7 run
+// ONE BARRIER BEHIND waves 0-3.  Waves w and w+4 share a SIMD, so each SIMD always
+// has one wave in its MFMA cluster while the partner reads LDS, waits and syncs: the
+// barrier wait of one group is the compute time of the other
+// (MI355X_MICROARCH.md "Two waves per SIMD"; guide section 5, 8-phase template).
+// The LDS latency of a LOAD segment is waited for AFTER its barrier.  Because the
+// groups are one segment apart, a half-operand is confirmed landed (own vmcnt, then
+// a barrier) one phase before the phase that reads it; DMA issue schedule as in the
+// overlapped kernel above.  GL = number of the phase's two DMA instructions issued in
+// the LOAD segment (the rest go between the MFMAs).
+// Diagnostic stamps (ABL == 7 build only): per wave, cycles summed over the K loop for
+// [0] load segment + its barrier wait, [1] compute segment, [2] barrier wait after compute.
+__device__ unsigned long long g_stamp[6 * 16384];
+AACLIP_DEV unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+// ABL (timing-only ablations, wrong results): 1 no DMA waits, 2 no DMA issue in the K loop,
+// 3 no LDS fragment reads in the K loop, 4 no barriers in the K loop, 5 = 2+3, 6 = 2+3+4.
+template <typename T, int EPI, int GL, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int PN, int patches_n, int total_patches) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[131072];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = (p.M + 255) >> 8;
+  int tm, tn;
+  {
+    const int P = 8 * PN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gp = (j / P) * 8 + xcd, local = j % P;
+    if (gp >= total_patches) return;
+    const int pm = gp / patches_n, pn = gp - pm * patches_n;
+    tm = pm * 8 + local / PN;
+    tn = pn * PN + local % PN;
+    if (tm >= tiles_m) return;
+  }
+  int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      const int ga = (idx & 7) + (idx >> 3) * 16 + sub * 8;
+      const int gw = (idx & 3) + (idx >> 2) * 8 + sub * 4;
+      int row, chunk;
+      tile_src_id(ga * 64 + lane, row, chunk);
+      int ar = tm * 256 + row;
+      ar = ar < p.M ? ar : p.M - 1;
+      srcA[sub][j] = (ar - tm * 256) * (int)p.lda + chunk * 8;
+      dstA[sub][j] = ga * 1024;
+      tile_src_id(gw * 64 + lane, row, chunk);
+      srcW[sub][j] = row * p.K + chunk * 8;
+      dstW[sub][j] = 32768 + gw * 1024;
+    }
+  const T* baseA = (const T*)p.A + (long)tm * 256 * p.lda;
+  const T* baseW = (const T*)p.W + (long)tn * 256 * p.K;
+  int offM[2][2], offN[2][2];   // [ks][tile parity]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      offM[ks][par] = tile_off_id(wr * 128 + par * 16 + c16, 4 * ks + q4);
+      offN[ks][par] = 32768 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 6;
+#define G1(base, src, dst, st, kt) glds16(base + src + (kt) * 64, smem + (st) * 65536 + dst);
+#define GA(sub, st, kt) { G1(baseA, srcA[sub][0], dstA[sub][0], st, kt) G1(baseA, srcA[sub][1], dstA[sub][1], st, kt) }
+#define GW(sub, st, kt) { G1(baseW, srcW[sub][0], dstW[sub][0], st, kt) G1(baseW, srcW[sub][1], dstW[sub][1], st, kt) }
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define BAR __builtin_amdgcn_s_barrier();
+#define PINB __builtin_amdgcn_sched_barrier(0);
+#define LD_M(sb, a)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) \
+      fm[t][ks] = *(const vec8*)((sb) + offM[ks][t & 1] + ((a) * 2 + (t >> 1)) * 4096);
+#define LD_N(sb, b)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 2; ++t) \
+      fn[t][ks] = *(const vec8*)((sb) + offN[ks][t] + (b) * 4096);
+#define MM(a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(fn[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+// COMPUTE segment: 16 MFMAs, DMA instructions I0 / I1 after the 4th / 10th
+#define QUADV(a, b, I0, I1)                                                  \
+  {                                                                          \
+    LGKM0                                                                    \
+    PINB                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                           \
+    MM(a, b, 0, 0, 0) MM(a, b, 0, 1, 0) MM(a, b, 1, 0, 0) MM(a, b, 1, 1, 0)  \
+    PINB I0 PINB                                                             \
+    MM(a, b, 2, 0, 0) MM(a, b, 2, 1, 0) MM(a, b, 3, 0, 0) MM(a, b, 3, 1, 0)  \
+    MM(a, b, 0, 0, 1) MM(a, b, 0, 1, 1)                                      \
+    PINB I1 PINB                                                             \
+    MM(a, b, 1, 0, 1) MM(a, b, 1, 1, 1) MM(a, b, 2, 0, 1) MM(a, b, 2, 1, 1)  \
+    MM(a, b, 3, 0, 1) MM(a, b, 3, 1, 1)                                      \
+    __builtin_amdgcn_s_setprio(0);                                           \
+    PINB                                                                     \
+  }
+// the phase's two DMA instructions: the first GL of them in the LOAD segment
+#define DL0(X) if (GL >= 1) { X }
+#define DL1(X) if (GL >= 2) { X }
+#define DC0(X) if (GL < 1) { X }
+#define DC1(X) if (GL < 2) { X }
+
+  // prologue: tile 0 in consumption order plus A0 of tile 1; A0,B0(0) confirmed by everyone
+  GA(0, 0, 0) GW(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
+  if (nk > 1) GA(0, 1, 1)
+  if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
+  BAR
+  if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
+
+  vec8 fm[4][2], fn[2][2];
+  constexpr bool NO_WAIT = ABL == 1, NO_DMA = ABL == 2 || ABL == 5 || ABL == 6, NO_LDS = ABL == 3 || ABL == 5 || ABL == 6,
+                 NO_BAR = ABL == 4 || ABL == 6;
+  constexpr bool STAMP = ABL == 7;
+  unsigned long long tl = 0, tc = 0, tb = 0, t_prev = 0, t_a = 0, t_b = 0, tw = 0, tr = 0, tg = 0;
+  if (STAMP) t_prev = stamp();
+  if (NO_LDS) { LD_M(smem, 0) LD_N(smem, 0) }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more1 = kt + 1 < nk && !NO_DMA, more2 = kt + 2 < nk && !NO_DMA;
+    const char* sb = smem + cur * 65536;
+    // ---- P0: load A0,B0(kt) fragments; confirm B1(kt) (younger: A1(kt) [, A0(kt+1)]); DMA B0(kt+1)
+    unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+    if (STAMP) { PINB u0 = stamp(); PINB }
+    if (!NO_WAIT) { if (more1) WAIT_VM(4); else WAIT_VM(2); }
+    if (STAMP) { PINB u1 = stamp(); PINB }
+    if (!NO_LDS) { LD_N(sb, 0) }
+    if (!NO_LDS) { LD_M(sb, 0) }
+    if (STAMP) { PINB u2 = stamp(); PINB }
+    DL0(if (more1) G1(baseW, srcW[0][0], dstW[0][0], nxt, kt + 1)) DL1(if (more1) G1(baseW, srcW[0][1], dstW[0][1], nxt, kt + 1))
+    if (STAMP) { PINB u3 = stamp(); PINB tw += u1 - u0; tr += u2 - u1; tg += u3 - u2; }
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_a = stamp(); PINB tl += t_a - t_prev; }
+    QUADV(0, 0, DC0(if (more1) G1(baseW, srcW[0][0], dstW[0][0], nxt, kt + 1)), DC1(if (more1) G1(baseW, srcW[0][1], dstW[0][1], nxt, kt + 1)))
+    if (STAMP) { PINB t_b = stamp(); PINB tc += t_b - t_a; }
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_prev = stamp(); PINB tb += t_prev - t_b; }
+    // ---- P1: load B1(kt); confirm A1(kt) (younger: [A0(kt+1), B0(kt+1)]); DMA B1(kt+1)
+    if (!NO_WAIT) { if (more1) WAIT_VM(4); else WAIT_VM(0); }
+    if (!NO_LDS) { LD_N(sb, 1) }
+    DL0(if (more1) G1(baseW, srcW[1][0], dstW[1][0], nxt, kt + 1)) DL1(if (more1) G1(baseW, srcW[1][1], dstW[1][1], nxt, kt + 1))
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_a = stamp(); PINB tl += t_a - t_prev; }
+    QUADV(0, 1, DC0(if (more1) G1(baseW, srcW[1][0], dstW[1][0], nxt, kt + 1)), DC1(if (more1) G1(baseW, srcW[1][1], dstW[1][1], nxt, kt + 1)))
+    if (STAMP) { PINB t_b = stamp(); PINB tc += t_b - t_a; }
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_prev = stamp(); PINB tb += t_prev - t_b; }
+    // ---- P2: load A1(kt); DMA A1(kt+1)
+    if (!NO_LDS) { LD_M(sb, 1) }
+    DL0(if (more1) G1(baseA, srcA[1][0], dstA[1][0], nxt, kt + 1)) DL1(if (more1) G1(baseA, srcA[1][1], dstA[1][1], nxt, kt + 1))
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_a = stamp(); PINB tl += t_a - t_prev; }
+    QUADV(1, 1, DC0(if (more1) G1(baseA, srcA[1][0], dstA[1][0], nxt, kt + 1)), DC1(if (more1) G1(baseA, srcA[1][1], dstA[1][1], nxt, kt + 1)))
+    if (STAMP) { PINB t_b = stamp(); PINB tc += t_b - t_a; }
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_prev = stamp(); PINB tb += t_prev - t_b; }
+    // ---- P3: re-load B0(kt); confirm A0,B0(kt+1) (younger: B1(kt+1), A1(kt+1)); DMA A0(kt+2)
+    if (!NO_WAIT) { if (more1) WAIT_VM(4); }
+    if (!NO_LDS) { LD_N(sb, 0) }
+    DL0(if (more2) G1(baseA, srcA[0][0], dstA[0][0], cur, kt + 2)) DL1(if (more2) G1(baseA, srcA[0][1], dstA[0][1], cur, kt + 2))
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_a = stamp(); PINB tl += t_a - t_prev; }
+    QUADV(1, 0, DC0(if (more2) G1(baseA, srcA[0][0], dstA[0][0], cur, kt + 2)), DC1(if (more2) G1(baseA, srcA[0][1], dstA[0][1], cur, kt + 2)))
+    if (STAMP) { PINB t_b = stamp(); PINB tc += t_b - t_a; }
+    if (!NO_BAR) BAR
+    if (STAMP) { PINB t_prev = stamp(); PINB tb += t_prev - t_b; }
+  }
+  if (wr == 0) BAR   // balance the barrier count of the two groups
+  if (ABL == 7 && lane == 0) {
+    const int w = (blockIdx.x * 8 + wave) & 16383;
+    g_stamp[6 * w + 0] = tl; g_stamp[6 * w + 1] = tc; g_stamp[6 * w + 2] = tb;
+    g_stamp[6 * w + 3] = tw; g_stamp[6 * w + 4] = tr; g_stamp[6 * w + 5] = tg;
+  }
+#undef G1
+#undef GA
+#undef GW
+#undef WAIT_VM
+#undef LGKM0
+#undef BAR
+#undef PINB
+#undef LD_M
+#undef LD_N
+#undef MM
+#undef QUADV
+#undef DL0
+#undef DL1
+#undef DC0
+#undef DC1
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Staggered + overlapped: the LOAD segment only waits for DMA and issues the two
+// DMA instructions of the phase; the LDS fragment reads of the next quadrant ride
+// inside the MFMA cluster (in-place, as in gemm16_256u_kernel).  With waves 4-7 one
+// barrier behind, a half-operand read during compute segment C(p) must have been
+// confirmed in L(p-1) by both groups:
+//   issue    A0(t+1)@L(t-1,P3)  B0(t+1)@L(t,P0)  B1(t+1)@L(t,P1)  A1(t+1)@L(t,P2)
+//   confirm  A1(t)@L(t,P0)      A0,B0(t+1)@L(t,P2)               B1(t+1)@L(t,P3)
+//   read     B1(t) in C(t,P0)   A1(t) in C(t,P1)   B0(t) in C(t,P2)   A0,B0(t+1) in C(t,P3)
+// every wait is vmcnt(2): one younger half-operand stays in flight behind it.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm16_256w_kernel(GemmParams p, int PN, int patches_n, int total_patches) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[131072];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = (p.M + 255) >> 8;
+  int tm, tn;
+  {
+    const int P = 8 * PN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gp = (j / P) * 8 + xcd, local = j % P;
+    if (gp >= total_patches) return;
+    const int pm = gp / patches_n, pn = gp - pm * patches_n;
+    tm = pm * 8 + local / PN;
+    tn = pn * PN + local % PN;
+    if (tm >= tiles_m) return;
+  }
+  int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      const int ga = (idx & 7) + (idx >> 3) * 16 + sub * 8;
+      const int gw = (idx & 3) + (idx >> 2) * 8 + sub * 4;
+      int row, chunk;
+      tile_src_id(ga * 64 + lane, row, chunk);
+      int ar = tm * 256 + row;
+      ar = ar < p.M ? ar : p.M - 1;
+      srcA[sub][j] = (ar - tm * 256) * (int)p.lda + chunk * 8;
+      dstA[sub][j] = ga * 1024;
+      tile_src_id(gw * 64 + lane, row, chunk);
+      srcW[sub][j] = row * p.K + chunk * 8;
+      dstW[sub][j] = 32768 + gw * 1024;
+    }
+  const T* baseA = (const T*)p.A + (long)tm * 256 * p.lda;
+  const T* baseW = (const T*)p.W + (long)tn * 256 * p.K;
+  int offM[2][2], offN[2][2];   // [ks][tile parity]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      offM[ks][par] = tile_off_id(wr * 128 + par * 16 + c16, 4 * ks + q4);
+      offN[ks][par] = 32768 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 6;
+#define G1(base, src, dst, st, kt) glds16(base + src + (kt) * 64, smem + (st) * 65536 + dst);
+#define GA(sub, st, kt) { G1(baseA, srcA[sub][0], dstA[sub][0], st, kt) G1(baseA, srcA[sub][1], dstA[sub][1], st, kt) }
+#define GW(sub, st, kt) { G1(baseW, srcW[sub][0], dstW[sub][0], st, kt) G1(baseW, srcW[sub][1], dstW[sub][1], st, kt) }
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define BAR __builtin_amdgcn_s_barrier();
+#define PINB __builtin_amdgcn_sched_barrier(0);
+#define RM(sb, a, t, ks) fm[t][ks] = *(const vec8*)((sb) + offM[ks][(t) & 1] + ((a) * 2 + ((t) >> 1)) * 4096);
+#define RN(sb, b, u, ks) fn[u][ks] = *(const vec8*)((sb) + offN[ks][u] + (b) * 4096);
+#define MM(a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(fn[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+#define SLOT(a, b, ks, t, X) MM(a, b, t, 0, ks) MM(a, b, t, 1, ks) PINB X PINB
+#define CW_NEWN(a, b, sn, nb)                                                            \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    SLOT(a, b, 0, 0, ) SLOT(a, b, 0, 1, ) SLOT(a, b, 0, 2, )                             \
+    SLOT(a, b, 0, 3, RN(sn, nb, 0, 0) RN(sn, nb, 1, 0))                                  \
+    SLOT(a, b, 1, 0, ) SLOT(a, b, 1, 1, ) SLOT(a, b, 1, 2, )                             \
+    SLOT(a, b, 1, 3, RN(sn, nb, 0, 1) RN(sn, nb, 1, 1))                                  \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+#define CW_NEWM(a, b, sn, na)                                                            \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    SLOT(a, b, 0, 0, RM(sn, na, 0, 0)) SLOT(a, b, 0, 1, RM(sn, na, 1, 0))                \
+    SLOT(a, b, 0, 2, RM(sn, na, 2, 0)) SLOT(a, b, 0, 3, RM(sn, na, 3, 0))                \
+    SLOT(a, b, 1, 0, RM(sn, na, 0, 1)) SLOT(a, b, 1, 1, RM(sn, na, 1, 1))                \
+    SLOT(a, b, 1, 2, RM(sn, na, 2, 1)) SLOT(a, b, 1, 3, RM(sn, na, 3, 1))                \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+#define CW_NEWMN(a, b, sn, na, nb)                                                       \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    SLOT(a, b, 0, 0, RM(sn, na, 0, 0)) SLOT(a, b, 0, 1, RM(sn, na, 1, 0))                \
+    SLOT(a, b, 0, 2, RM(sn, na, 2, 0))                                                   \
+    SLOT(a, b, 0, 3, RM(sn, na, 3, 0) RN(sn, nb, 0, 0) RN(sn, nb, 1, 0))                 \
+    SLOT(a, b, 1, 0, RM(sn, na, 0, 1)) SLOT(a, b, 1, 1, RM(sn, na, 1, 1))                \
+    SLOT(a, b, 1, 2, RM(sn, na, 2, 1))                                                   \
+    SLOT(a, b, 1, 3, RM(sn, na, 3, 1) RN(sn, nb, 0, 1) RN(sn, nb, 1, 1))                 \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+#define CW_LAST(a, b)                                                                    \
+  {                                                                                      \
+    SLOT(a, b, 0, 0, ) SLOT(a, b, 0, 1, ) SLOT(a, b, 0, 2, ) SLOT(a, b, 0, 3, )          \
+    SLOT(a, b, 1, 0, ) SLOT(a, b, 1, 1, ) SLOT(a, b, 1, 2, ) SLOT(a, b, 1, 3, )          \
+  }
+
+  // prologue: tile 0 in consumption order plus A0 of tile 1; A0,B0,B1(0) confirmed by everyone
+  GA(0, 0, 0) GW(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
+  if (nk > 1) GA(0, 1, 1)
+  vec8 fm[4][2], fn[2][2];
+  if (nk > 1) WAIT_VM(4); else WAIT_VM(2);
+  BAR
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) RM(smem, 0, t, ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) RN(smem, 0, u, ks)
+  }
+  if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    const char* sb = smem + cur * 65536;
+    const char* sn = smem + nxt * 65536;
+    // ---- P0: confirm A1(kt) (younger: A0(kt+1)); issue B0(kt+1); compute (A0,B0) while reading B1(kt)
+    if (more1) WAIT_VM(2); else WAIT_VM(0);
+    if (more1) GW(0, nxt, kt + 1)
+    BAR
+    CW_NEWN(0, 0, sb, 1)
+    BAR
+    // ---- P1: issue B1(kt+1); compute (A0,B1) while reading A1(kt)
+    if (more1) GW(1, nxt, kt + 1)
+    BAR
+    CW_NEWM(0, 1, sb, 1)
+    BAR
+    // ---- P2: confirm A0,B0(kt+1) (younger: B1(kt+1)); issue A1(kt+1); compute (A1,B1) while re-reading B0(kt)
+    if (more1) { WAIT_VM(2); GA(1, nxt, kt + 1) }
+    BAR
+    CW_NEWN(1, 1, sb, 0)
+    BAR
+    // ---- P3: confirm B1(kt+1) (younger: A1(kt+1)); issue A0(kt+2); compute (A1,B0) while reading A0,B0(kt+1)
+    if (more1) WAIT_VM(2);
+    if (more2) GA(0, cur, kt + 2)
+    BAR
+    if (more1) CW_NEWMN(1, 0, sn, 0, 0) else CW_LAST(1, 0)
+    BAR
+  }
+  if (wr == 0) BAR   // balance the barrier count of the two groups
+#undef G1
+#undef GA
+#undef GW
+#undef WAIT_VM
+#undef BAR
+#undef PINB
+#undef RM
+#undef RN
+#undef MM
+#undef SLOT
+#undef CW_NEWN
+#undef CW_NEWM
+#undef CW_NEWMN
+#undef CW_LAST
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+}
+
 template <typename T>
-static void launch_t(int epi, const GemmParams& p, hipStream_t s) {
+static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped) {
   const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
   const int PN = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0) ? 3 : (tiles_n % 2 == 0) ? 2 : 1;
   const int patches_n = tiles_n / PN, patches_m = (tiles_m + 7) / 8;
   const int total = patches_n * patches_m;
   const int grid = ((total + 7) / 8) * 8 * 8 * PN;
   dim3 g(grid), b(512);
+  if (overlapped == 12) {   // staggered + overlapped LDS reads
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_BIAS_RESID>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_ACT_F32>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_PATCH: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_PATCH>), g, b, 0, s, p, PN, patches_n, total); break;
+    }
+    return;
+  }
+  if (overlapped >= 5 && epi == EPI_ACT_F32) {   // timing ablations of the staggered kernel (GL = 2)
+    switch (overlapped) {
+      case 5: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 1>), g, b, 0, s, p, PN, patches_n, total); break;
+      case 6: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 2>), g, b, 0, s, p, PN, patches_n, total); break;
+      case 7: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 3>), g, b, 0, s, p, PN, patches_n, total); break;
+      case 8: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 4>), g, b, 0, s, p, PN, patches_n, total); break;
+      case 9: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 5>), g, b, 0, s, p, PN, patches_n, total); break;
+      case 10: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 6>), g, b, 0, s, p, PN, patches_n, total); break;
+      default: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 7>), g, b, 0, s, p, PN, patches_n, total); break;
+    }
+    return;
+  }
+  if (overlapped >= 5) overlapped = 4;
+  if (overlapped >= 2) {   // staggered kernel, GL = overlapped - 2 DMA instructions in the load segment
+#define LV(E) { if (overlapped == 2) hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 0>), g, b, 0, s, p, PN, patches_n, total); \
+               else if (overlapped == 3) hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 1>), g, b, 0, s, p, PN, patches_n, total); \
+               else hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 2>), g, b, 0, s, p, PN, patches_n, total); }
+    switch (epi) {
+      case EPI_BIAS: LV(EPI_BIAS) break;
+      case EPI_BIAS_GELU: LV(EPI_BIAS_GELU) break;
+      case EPI_BIAS_RESID: LV(EPI_BIAS_RESID) break;
+      case EPI_ACT_F32: LV(EPI_ACT_F32) break;
+      case EPI_PATCH: LV(EPI_PATCH) break;
+    }
+#undef LV
+    return;
+  }
+  if (overlapped) {
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_BIAS_RESID>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_ACT_F32>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_PATCH: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_PATCH>), g, b, 0, s, p, PN, patches_n, total); break;
+    }
+    return;
+  }
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -264,9 +865,23 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s) {
   }
 }
 
-void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s) {
-  if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s);
-  else launch_t<bf16>(epi, p, s);
+void read_gemm_stamps(double* out6, int nwaves) {
+  static unsigned long long host[6 * 16384];
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(host));
+  if (nwaves > 16384) nwaves = 16384;
+  double sum[6] = {0, 0, 0, 0, 0, 0};
+  int n = 0;
+  for (int i = 0; i < nwaves; ++i) {
+    if (host[6 * i + 1] == 0) continue;
+    for (int j = 0; j < 6; ++j) sum[j] += (double)host[6 * i + j];
+    ++n;
+  }
+  for (int j = 0; j < 6; ++j) out6[j] = n ? sum[j] / n : 0;
+}
+
+void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped) {
+  if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped);
+  else launch_t<bf16>(epi, p, s, overlapped);
 }
 
 }  // namespace aaclip

@@ -28,8 +28,9 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p);
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s);
 bool gemm256_applicable(int dtype, const GemmParams& p);
 void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined);
-void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s);
+void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped);
 void set_gemm_variant(int v);
+void read_gemm_stamps(double* out3, int nwaves);
 void set_attn_variant(int v);
 
 // fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]

@@ -25,7 +25,7 @@ shapes = [("qkv", _lib.EPI_BIAS, 3072, 1024), ("out_proj", _lib.EPI_BIAS_RESID, 
           ("k4096_f32out", _lib.EPI_ACT_F32, 1024, 4096), ("n4096_f32out", _lib.EPI_ACT_F32, 4096, 1024)]
 if a.only:
     shapes = [s for s in shapes if s[0] in a.only.split(",")]
-if any(v in (4, 5) for v in [int(v) for v in a.variants.split(",")]):
+if any(v in (4, 5, 11, 12, 13, 14, 15, 16) for v in [int(v) for v in a.variants.split(",")]):
     shapes = [s for s in shapes if s[1] == _lib.EPI_ACT_F32]   # timing ablations exist for the fp32-out epilogue only
 variants = [int(v) for v in a.variants.split(",")]
 st = torch.cuda.current_stream().cuda_stream
