@@ -62,11 +62,12 @@ def require_gpu(t: torch.Tensor, what: str) -> None:
 class Workspace:
     """One growing scratch buffer per device (caller-owned as far as the C ABI
     is concerned)."""
-    _bufs: Dict[int, torch.Tensor] = {}
+    _bufs: Dict[tuple, torch.Tensor] = {}
 
     @classmethod
     def get(cls, dev: torch.device, nbytes: int) -> torch.Tensor:
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        idx = (idx, torch.cuda.current_stream(dev).cuda_stream)   # one scratch buffer per (device, stream)
         buf = cls._bufs.get(idx)
         if buf is None or buf.numel() < nbytes:
             cls._bufs[idx] = None

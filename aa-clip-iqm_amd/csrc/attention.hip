@@ -481,6 +481,262 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Software-pipelined variant (32 query rows per wave, 4-stage K/V ring): the
+// S^T MFMA chain of key tile j+1 is issued BEFORE the exponentials of tile j and
+// the compiler is told (sched_group_barrier) to interleave one MFMA with a slice
+// of the softmax VALU work, so the matrix pipe and the VALU run concurrently
+// inside one wave instead of in turns (guide T15/T19).  The running maximum used
+// for tile j+1's accumulator start is the one AFTER tile j's re-base, so the
+// arithmetic is identical to the kernels above.
+template <typename T, bool LOG2Q>
+__global__ __launch_bounds__(256, 2) void attn16p_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
+                                                         int causal) {
+  typedef typename Elem<T>::vec8 vec8;
+  typedef typename Elem<T>::vec4 vec4;
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) char smem[65536];  // 4 stages x (K 8K + V 8K)
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const T* base = qkv + (long)b * L * ld + head * 64;
+  const int q0 = qt * 128 + wave * 32;
+  const int qi = q0 + r;
+  const int qrow = qi < L ? qi : L - 1;
+
+  vec8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
+
+  const T* ksrc[2];
+  const T* vsrc[2];
+  int drow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pslot = (wave * 2 + j) * 64 + lane;
+    const int row = pslot >> 3, sl = pslot & 7;
+    drow[j] = row;
+    ksrc[j] = base + (long)row * ld + D + (sl ^ xk(row)) * 8;
+    vsrc[j] = base + (long)row * ld + 2 * D + (sl ^ xv(row)) * 8;
+  }
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ xk(r)) << 4);
+  int voff[2];
+  {
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+    const int row = 4 * (g >> 1) + qq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
+      voff[db] = 8192 + row * 128 + ((chunk ^ xv(row)) << 4) + (pp & 1) * 8;
+    }
+  }
+  int last_q = qt * 128 + 127;
+  if (last_q > L - 1) last_q = L - 1;
+  const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
+
+  auto stage = [&](int st, int kt) {
+    char* dst = smem + st * 16384 + wave * 2048;
+    const long step = (long)kt * 64 * ld;
+    if (kt * 64 + 64 <= L) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        glds16(ksrc[j] + step, dst + j * 1024);
+        glds16(vsrc[j] + step, dst + 8192 + j * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int over = kt * 64 + drow[j] - (L - 1);
+        over = over > 0 ? over : 0;
+        glds16(ksrc[j] + step - (long)over * ld, dst + j * 1024);
+        glds16(vsrc[j] + step - (long)over * ld, dst + 8192 + j * 1024);
+      }
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float m2 = 0.f, l = 0.f;
+
+  // mask (tail / causal) + scaling for the non-log2 contract + tile maximum
+  auto finish_scores = [&](f32x16 (&s)[2], int kt) -> float {
+    if (!LOG2Q) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = fmaf(s[sub][e], LOG2E, -m2);
+    }
+    const int k0 = kt * 64;
+    const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));
+    if (need_mask) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int key = k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          bool dead = (key >= L) || (causal && key > qi);
+          s[sub][e] = dead ? -INFINITY : s[sub][e];
+        }
+    }
+    float a = s[0][0], c = s[1][0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) {
+      a = fmaxf(a, s[0][e]);
+      c = fmaxf(c, s[1][e]);
+    }
+    a = fmaxf(a, c);
+    return fmaxf(a, __shfl_xor(a, 32, 64));
+  };
+
+// S'^T(next) = K . Q^T - m2 : 8 LDS reads, then 8 MFMAs interleaved with the exponentials of the current tile
+#define QK_EXP(SB, SNEXT, SCUR, WITH_QK)                                                      \
+  {                                                                                           \
+    vec8 kf[2][4];                                                                            \
+    if (WITH_QK) {                                                                            \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                      \
+        kf[0][ks] = *(const vec8*)((SB) + koff[ks]);                                          \
+        kf[1][ks] = *(const vec8*)((SB) + koff[ks] + 4096);                                   \
+      }                                                                                       \
+      _Pragma("unroll") for (int sub = 0; sub < 2; ++sub)                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) SNEXT[sub][e] = LOG2Q ? -m2 : 0.f;     \
+    }                                                                                         \
+    float ra = 0.f, rb = 0.f;                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                        \
+      if (WITH_QK) {                                                                          \
+        SNEXT[0] = Elem<T>::mma32(kf[0][ks], qf[ks], SNEXT[0]);                               \
+        SNEXT[1] = Elem<T>::mma32(kf[1][ks], qf[ks], SNEXT[1]);                               \
+      }                                                                                       \
+      _Pragma("unroll") for (int e = 4 * ks; e < 4 * ks + 4; ++e) {                           \
+        float pa = __builtin_amdgcn_exp2f(SCUR[0][e]);                                        \
+        float pb = __builtin_amdgcn_exp2f(SCUR[1][e]);                                        \
+        SCUR[0][e] = pa; SCUR[1][e] = pb;                                                     \
+        ra += pa; rb += pb;                                                                   \
+      }                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);   /* keep 2 MFMAs + 8 exponentials per slice */      \
+    }                                                                                         \
+    ra += rb;                                                                                 \
+    l += ra + __shfl_xor(ra, 32, 64);                                                         \
+  }
+
+  auto pv = [&](const char* sb, f32x16 (&s)[2]) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        vec8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = from_float<T>(s[sub][8 * s2 + j]);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
+          i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = Elem<T>::mma32(__builtin_bit_cast(vec8, both), pf, o[db]);
+        }
+      }
+  };
+
+  auto rebase = [&](f32x16 (&s)[2], float mt, bool first) {
+    if (first || __any(mt > 0.f)) {
+      const float delta = first ? mt : fmaxf(mt, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m2 += delta;
+      l *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+    }
+  };
+
+  // ring prologue: up to three tiles in flight; tile 0 visible
+  stage(0, 0);
+  if (nkt > 1) stage(1, 1);
+  if (nkt > 2) stage(2, 2);
+  if (nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x16 sA[2], sB[2];
+  {  // S(0)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sA[sub][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sA[sub] = Elem<T>::mma32(*(const vec8*)(smem + koff[ks] + sub * 4096), qf[ks], sA[sub]);
+    }
+  }
+  float mt = finish_scores(sA, 0);
+
+// one key tile that has a successor: SCUR holds S'(t); S'(t+1) is computed into SNEXT while SCUR is exponentiated
+#define PIPE_STEP(i, SCUR, SNEXT)                                                  \
+  {                                                                                \
+    const int t = kt + (i);                                                        \
+    if (t + 1 >= nkt) break;                                                       \
+    /* make tile t+1 visible, free the stage of tile t-1 */                        \
+    if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+    __builtin_amdgcn_s_barrier();                                                  \
+    if (t + 3 < nkt) stage(((i) + 3) & 3, t + 3);                                  \
+    rebase(SCUR, mt, t == 0);                                                      \
+    QK_EXP(smem + (((i) + 1) & 3) * 16384, SNEXT, SCUR, true)                      \
+    pv(smem + ((i) & 3) * 16384, SCUR);                                            \
+    mt = finish_scores(SNEXT, t + 1);                                              \
+  }
+  for (int kt = 0; kt < nkt; kt += 4) {
+    PIPE_STEP(0, sA, sB)
+    PIPE_STEP(1, sB, sA)
+    PIPE_STEP(2, sA, sB)
+    PIPE_STEP(3, sB, sA)
+  }
+  {  // last tile (no successor): its scores sit in sA for an even tile index, sB for an odd one
+    const int t = nkt - 1;
+    const char* sb = smem + (t & 3) * 16384;
+    if (t & 1) {
+      rebase(sB, mt, t == 0);
+      QK_EXP(smem, sA, sB, false)
+      pv(sb, sB);
+    } else {
+      rebase(sA, mt, t == 0);
+      QK_EXP(smem, sB, sA, false)
+      pv(sb, sA);
+    }
+  }
+#undef PIPE_STEP
+#undef QK_EXP
+
+  if (qi < L) {
+    const float inv = 1.0f / l;
+    T* dst = ctx + ((long)b * L + qi) * D + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        vec4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = from_float<T>(o[db][4 * gi + j] * inv);
+        *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = v;
+      }
+  }
+}
+
 // ------------------------------------------------------------------ fp32 path
 __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L,
                                                      int H, int causal) {
@@ -584,6 +840,15 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
   if (dtype == AACLIP_F32) {
     dim3 g((L + 255) / 256, H, B);
     hipLaunchKernelGGL(attn32_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
+  } else if (L >= 512 && g_attn_variant == 2) {   // software-pipelined kernel
+    dim3 g((L + 127) / 128, H, B);
+    if (dtype == AACLIP_F16) {
+      if (log2q) hipLaunchKernelGGL((attn16p_kernel<f16, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16p_kernel<f16, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    } else {
+      if (log2q) hipLaunchKernelGGL((attn16p_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16p_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+    }
   } else if (L >= 512 && g_attn_variant != 1) {
     dim3 g((L + 255) / 256, H, B);
     if (dtype == AACLIP_F16) {

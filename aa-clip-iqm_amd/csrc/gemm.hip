@@ -252,9 +252,9 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {
-    if (g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 18)) {
+    if (g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 19)) {
       // 16x16x32 MFMA shape; 6 plain, 7 overlapped LDS reads, 8/9/10 staggered with 0/1/2 DMA issues in the load segment; 11..16 timing ablations of 10 (fp32-out epilogue only)
-      launch_gemm256t(dtype, epi, p, s, g_gemm_variant == 0 ? 4 : g_gemm_variant - 6);   // default: staggered, both DMA issues in the load segment
+      launch_gemm256t(dtype, epi, p, s, g_gemm_variant == 0 ? 13 : g_gemm_variant - 6);   // default: staggered, DMA by buffer_load in the load segment
       return;
     }
     // 0/3: DMA issued between the MFMAs (default); 2: DMA at the phase start; 4, 5: timing ablations

@@ -443,7 +443,9 @@ AACLIP_DEV unsigned long long stamp() {
 }
 // ABL (timing-only ablations, wrong results): 1 no DMA waits, 2 no DMA issue in the K loop,
 // 3 no LDS fragment reads in the K loop, 4 no barriers in the K loop, 5 = 2+3, 6 = 2+3+4.
-template <typename T, int EPI, int GL, int ABL = 0>
+// BUF: issue the DMA as buffer_load ... lds (wave-uniform base in the descriptor, 32-bit per-lane
+// byte offset, K-tile advance in the scalar offset: no VALU address arithmetic per DMA).
+template <typename T, int EPI, int GL, int ABL = 0, bool BUF = false>
 __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int PN, int patches_n, int total_patches) {
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[131072];
@@ -502,7 +504,18 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
   const int nk = p.K >> 6;
-#define G1(base, src, dst, st, kt) glds16(base + src + (kt) * 64, smem + (st) * 65536 + dst);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
+#define RS_baseA rsA
+#define RS_baseW rsW
+#define G1(base, src, dst, st, kt)                                                                       \
+  {                                                                                                      \
+    if (BUF)                                                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_##base, (lds_void*)(smem + (st) * 65536 + dst), 16,    \
+                                               (src) * 2, (kt) * 128, 0, 0);                             \
+    else                                                                                                 \
+      glds16(base + src + (kt) * 64, smem + (st) * 65536 + dst);                                         \
+  }
 #define GA(sub, st, kt) { G1(baseA, srcA[sub][0], dstA[sub][0], st, kt) G1(baseA, srcA[sub][1], dstA[sub][1], st, kt) }
 #define GW(sub, st, kt) { G1(baseW, srcW[sub][0], dstW[sub][0], st, kt) G1(baseW, srcW[sub][1], dstW[sub][1], st, kt) }
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -609,6 +622,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
     g_stamp[6 * w + 3] = tw; g_stamp[6 * w + 4] = tr; g_stamp[6 * w + 5] = tg;
   }
 #undef G1
+#undef RS_baseA
+#undef RS_baseW
 #undef GA
 #undef GW
 #undef WAIT_VM
@@ -809,6 +824,16 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
   const int total = patches_n * patches_m;
   const int grid = ((total + 7) / 8) * 8 * 8 * PN;
   dim3 g(grid), b(512);
+  if (overlapped == 13) {   // staggered, both DMA issues in the load segment, buffer_load ... lds
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_BIAS, 2, 0, true>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_BIAS_GELU, 2, 0, true>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_BIAS_RESID, 2, 0, true>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 0, true>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_PATCH: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_PATCH, 2, 0, true>), g, b, 0, s, p, PN, patches_n, total); break;
+    }
+    return;
+  }
   if (overlapped == 12) {   // staggered + overlapped LDS reads
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;

@@ -85,3 +85,45 @@ def image_score(det_feature: torch.Tensor, text_feature: torch.Tensor) -> torch.
     [B,B,2] and then row 1; B dot products, host-side."""
     t = text_feature if text_feature.dim() == 2 else text_feature[0]
     return (det_feature @ t[:, 1].to(det_feature.device) + 1) / 2
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation harness counterpart (host side: numpy + sklearn, like the reference)
+def metrics_eval(pixel_label, image_label, pixel_preds, image_preds, class_names, domain):
+    """Pixel / image AUROC and AP of one class, reference forward_utils.py:233-308:
+    global min-max normalisation of maps and image scores (:246-253), per-image maximum of
+    the normalised map (:277), Industrial score = 0.5*max_pixel + 0.5*image score, Medical =
+    max_pixel (:279-282), sklearn roc_auc_score / average_precision_score (:288-296).
+    `image_preds` is the per-image score vector [N] (this build computes the intended
+    (det . t_abnormal + 1)/2 score; the reference's [N,2] broadcast quirk, of which it keeps
+    column 0, is documented in DESIGN.md and accepted here too)."""
+    import numpy as np
+    from sklearn.metrics import average_precision_score, roc_auc_score
+
+    pixel_preds = np.asarray(pixel_preds, dtype=np.float64)
+    image_preds = np.asarray(image_preds, dtype=np.float64)
+    pixel_label = np.asarray(pixel_label)
+    image_label = np.asarray(image_label)
+    if pixel_preds.max() != 1:
+        pixel_preds = (pixel_preds - pixel_preds.min()) / (pixel_preds.max() - pixel_preds.min())
+    if image_preds.max() != 1:
+        image_preds = (image_preds - image_preds.min()) / (image_preds.max() - image_preds.min())
+    if pixel_preds.ndim == 4 and pixel_preds.shape[1] == 1:
+        pixel_preds = pixel_preds[:, 0]
+    if image_preds.ndim == 2 and image_preds.shape[1] == 2:
+        image_preds = image_preds[:, 0]
+    elif image_preds.ndim > 1:
+        image_preds = image_preds.reshape(-1)
+    pmax = pixel_preds.max(axis=(1, 2))
+    image_preds = pmax * 0.5 + image_preds * 0.5 if domain != "Medical" else pmax
+    pl, pp = pixel_label.reshape(-1), pixel_preds.reshape(-1)
+    pixel_auc = roc_auc_score(pl, pp)
+    pixel_ap = average_precision_score(pl, pp)
+    if image_label.max() != image_label.min():
+        il = image_label.reshape(-1)
+        image_auc = roc_auc_score(il, image_preds.reshape(-1))
+        image_ap = average_precision_score(il, image_preds.reshape(-1))
+    else:
+        image_auc = image_ap = 0
+    return {"class name": class_names, "pixel AUC": round(pixel_auc, 4) * 100, "pixel AP": round(pixel_ap, 4) * 100,
+            "image AUC": round(image_auc, 4) * 100, "image AP": round(image_ap, 4) * 100}

@@ -381,3 +381,41 @@ def test_batch_independence_and_determinism(dev, full_weights):
     for a, s in zip(seg_a, seg_1):
         assert torch.equal(a[3:4], s)
     assert torch.equal(det_a[3:4], det_1)
+
+
+# ----------------------------------------------------------------------------
+# metric parity: AUROC of the anomaly map on synthetic masks (no dataset in the container)
+# ----------------------------------------------------------------------------
+def test_auroc_parity_on_synthetic_masks(dev, full_weights):
+    """BASELINE.json: 'patch-anomaly-map AUROC parity'.  Pixel AUROC / AP of the HIP map vs
+    the oracle's map against the same synthetic ground-truth masks: |delta| <= 1e-3."""
+    import forward_utils as FU
+    from sklearn.metrics import roc_auc_score
+    cfg, sd, ia, ta = full_weights
+    model = build_full(dev, "fp16", full_weights)
+    B = 4
+    img = synth.synth_images(B, 518, seed=21)
+    masks = synth.synth_masks(B, 518, seed=21).numpy()
+    tok = torch.zeros(2, 77, dtype=torch.int32)
+    tok[0, :4] = torch.tensor([49406, 1125, 539, 49407])
+    tok[1, :5] = torch.tensor([49406, 320, 13568, 539, 49407])
+    with torch.no_grad():
+        seg, det, _ = model(img.to(dev))
+        txt = model.encode_text(tok.to(dev))
+        anchors = torch.stack([txt[0] / txt[0].norm(), txt[1] / txt[1].norm()], dim=1)
+        amap = FU.calculate_anomaly_map(seg, anchors, 518, domain="Industrial").cpu()
+        score = FU.image_score(det, anchors).cpu()
+    oseg, odet = O.adapted_visual_forward(img, sd, ia, cfg.vision.heads)
+    otxt = O.adapted_encode_text(tok, sd, ta, cfg.text.heads)
+    oanch = O.class_anchor(otxt[0:1], otxt[1:2])
+    omap = O.anomaly_map(oseg, oanch, 518, "Industrial")
+    oscore = O.image_score(odet, oanch)
+    assert_close(amap, omap, 2e-2, 1e-2, "anomaly map (x100 cosines, fp16 towers on both sides of the dot)")
+    a = roc_auc_score(masks.reshape(-1), amap.numpy().reshape(-1))
+    b = roc_auc_score(masks.reshape(-1), omap.numpy().reshape(-1))
+    assert abs(a - b) <= 1e-3, (a, b)
+    labels = np.array([0, 1, 0, 1])
+    r1 = FU.metrics_eval(masks, labels, amap.numpy(), score.numpy(), "synthetic", "Industrial")
+    r2 = FU.metrics_eval(masks, labels, omap.numpy(), oscore.numpy(), "synthetic", "Industrial")
+    for k in ("pixel AUC", "pixel AP"):
+        assert abs(r1[k] - r2[k]) <= 0.1 + 1e-9, (k, r1, r2)   # values are percentages rounded to 2 decimals
