@@ -91,6 +91,7 @@ int aaclip_profile_end(float* ms, int* tags, int max_n) {
 int aaclip_set_gemm_variant(int v) {
   set_gemm_variant(v & 0xFF);
   set_attn_variant((v >> 8) & 0xFF);   // bits 8..15: attention kernel selection
+  set_tail_peel(((v >> 16) & 1) ? 0 : 1);  // bit 16: disable tail peeling
   return 0;
 }
 

@@ -246,19 +246,50 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
   return nullptr;
 }
 
+static int g_tail_peel = 0;  // measured: not a win (the 128-tile kernel is too slow for the peeled rows)
+void set_tail_peel(int v) { g_tail_peel = v; }
 static int g_gemm_variant = 0;  // 0 auto, 1 force the 128-tile kernel, 2 force the 256-tile kernel where legal
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+
+static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+  if (g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60)) {
+    // 16x16x32 MFMA shape; 6 plain, 7 overlapped LDS reads, 8/9/10 staggered with 0/1/2 DMA issues in the load
+    // segment, 11..17 timing ablations / stamps of 10 (fp32-out epilogue only), 18 staggered + in-cluster reads,
+    // 19 (default) = 10 with buffer_load ... lds
+    launch_gemm256t(dtype, epi, p, s, g_gemm_variant == 0 ? 14 : g_gemm_variant - 6);
+    return;
+  }
+  // 32x32x16 kernels: 2 DMA at the phase start, 3 DMA between the MFMAs, 4/5 timing ablations
+  launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : (g_gemm_variant >= 3 ? g_gemm_variant - 2 : 1));
+}
 
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {
-    if (g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 19)) {
-      // 16x16x32 MFMA shape; 6 plain, 7 overlapped LDS reads, 8/9/10 staggered with 0/1/2 DMA issues in the load segment; 11..16 timing ablations of 10 (fp32-out epilogue only)
-      launch_gemm256t(dtype, epi, p, s, g_gemm_variant == 0 ? 13 : g_gemm_variant - 6);   // default: staggered, DMA by buffer_load in the load segment
-      return;
+    // Tail peeling: 256x256 tiles run one per CU in rounds of 256.  When the last round would be
+    // less than 60 % full, the rows of that partial round go to the 128-tile kernel instead (two
+    // workgroups per CU, finer granularity); both kernels produce bit-identical results.
+    const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
+    const long tiles = (long)tiles_m * tiles_n;
+    const long rem = tiles % 256;
+    if (g_tail_peel && epi != EPI_PATCH && tiles > 256 && rem > 0 && rem < 154) {
+      const int m_full = (int)((tiles - rem) / tiles_n);   // whole M tiles covered by full rounds
+      const long rows_full = (long)m_full * 256;
+      if (rows_full > 0 && rows_full < p.M) {
+        GemmParams a = p, b = p;
+        a.M = (int)rows_full;
+        const size_t es = 2, os = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? 2 : 4;
+        b.A = (const char*)p.A + rows_full * p.lda * es;
+        b.out = (char*)p.out + rows_full * p.ldc * os;
+        b.M = p.M - (int)rows_full;
+        launch_gemm_big(dtype, epi, a, s);
+        const int t128 = ((b.M + 127) / 128) * (b.N / 128);
+        if (dtype == AACLIP_F16) launch16<f16>(epi, b, dim3(t128), s);
+        else launch16<bf16>(epi, b, dim3(t128), s);
+        return;
+      }
     }
-    // 0/3: DMA issued between the MFMAs (default); 2: DMA at the phase start; 4, 5: timing ablations
-    launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : (g_gemm_variant >= 3 ? g_gemm_variant - 2 : 1));
+    launch_gemm_big(dtype, epi, p, s);
     return;
   }
   const int tiles = ((p.M + 127) / 128) * (p.N / 128);

@@ -450,6 +450,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[131072];
 
+  const unsigned long long t_entry = (ABL == 7) ? stamp() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
                  NO_BAR = ABL == 4 || ABL == 6;
   constexpr bool STAMP = ABL == 7;
   unsigned long long tl = 0, tc = 0, tb = 0, t_prev = 0, t_a = 0, t_b = 0, tw = 0, tr = 0, tg = 0;
-  if (STAMP) t_prev = stamp();
+  if (STAMP) { t_prev = stamp(); tw = t_prev - t_entry; }
   if (NO_LDS) { LD_M(smem, 0) LD_N(smem, 0) }
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
@@ -616,6 +617,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
     if (STAMP) { PINB t_prev = stamp(); PINB tb += t_prev - t_b; }
   }
   if (wr == 0) BAR   // balance the barrier count of the two groups
+  unsigned long long t_loop_end = 0;
+  if (ABL == 7) t_loop_end = stamp();
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+  if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr = stamp() - t_loop_end; }
   if (ABL == 7 && lane == 0) {
     const int w = (blockIdx.x * 8 + wave) & 16383;
     g_stamp[6 * w + 0] = tl; g_stamp[6 * w + 1] = tc; g_stamp[6 * w + 2] = tb;
@@ -638,7 +643,16 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
 #undef DL1
 #undef DC0
 #undef DC1
-  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+  if (ABL == 8) {   // timing ablation: no epilogue stores (one dummy store keeps the accumulators live)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 123.456f) ((float*)p.out)[0] = sum;
+  } else if (ABL != 7) {
+    epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -816,6 +830,180 @@ __global__ __launch_bounds__(512, 2) void gemm16_256w_kernel(GemmParams p, int P
   epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Staggered kernel with two N-side fragment sets (the default).  Tried on top of it and dropped
+// (no gain): a persistent workgroup walking the tile list (static order and per-XCD
+// atomic queues with stealing), start-time de-phasing of the first round, smaller XCD patches.  B0 stays in registers for the
+// whole K tile (no re-read in phase 3) and the next tile's B0 is read one phase
+// early into the set that B1 has just vacated, so a LOAD segment reads at most 8
+// fragments (12 before) and a K tile 24 (28 before).  DMA by buffer_load ... lds,
+// both in the LOAD segment.  Schedule (reads in L(p) must be confirmed in L(p-1)
+// by both wave groups):
+//   issue    A0(t+1)@L(t,P0)  B1(t+1)@L(t,P1)  A1(t+1)@L(t,P2)  B0(t+2)@L(t,P3)
+//   confirm  B1(t)@L(t,P0)    A1(t)@L(t,P1)    B0(t+1)@L(t,P2)  A0(t+1)@L(t,P3)
+//   read     A0(t)@L(t,P0)    B1(t)@L(t,P1)    A1(t)@L(t,P2)    B0(t+1)@L(t,P3)
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[131072];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = (p.M + 255) >> 8;
+  int tm, tn;
+  {
+    const int P = PM * PN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gp = (j / P) * 8 + xcd, local = j % P;
+    if (gp >= total_patches) return;
+    const int pm = gp / patches_n, pn = gp - pm * patches_n;
+    tm = pm * PM + local / PN;
+    tn = pn * PN + local % PN;
+    if (tm >= tiles_m) return;
+  }
+  if (stagger > 1 && blockIdx.x < 256) {
+    // De-phase the first round: workgroup slot k of an XCD starts k/stagger of a tile later, and the
+    // dispatcher keeps the CUs de-phased afterwards.  Otherwise every CU reaches its epilogue at the
+    // same moment and the residual read-modify-write (67 + 67 MB per round) is an HBM burst with no
+    // MFMA running beside it.
+    const int slot = (blockIdx.x >> 3) % stagger;
+    const long long target = (long long)slot * (p.K >> 6) * 2800 / stagger;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(64);
+  }
+  int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];   // byte offsets
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      const int ga = (idx & 7) + (idx >> 3) * 16 + sub * 8;
+      const int gw = (idx & 3) + (idx >> 2) * 8 + sub * 4;
+      int row, chunk;
+      tile_src_id(ga * 64 + lane, row, chunk);
+      int ar = tm * 256 + row;
+      ar = ar < p.M ? ar : p.M - 1;
+      srcA[sub][j] = ((ar - tm * 256) * (int)p.lda + chunk * 8) * 2;
+      dstA[sub][j] = ga * 1024;
+      tile_src_id(gw * 64 + lane, row, chunk);
+      srcW[sub][j] = (row * p.K + chunk * 8) * 2;
+      dstW[sub][j] = 32768 + gw * 1024;
+    }
+  const T* baseA = (const T*)p.A + (long)tm * 256 * p.lda;
+  const T* baseW = (const T*)p.W + (long)tn * 256 * p.K;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
+  int offM[2][2], offN[2][2];   // [ks][tile parity]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      offM[ks][par] = tile_off_id(wr * 128 + par * 16 + c16, 4 * ks + q4);
+      offN[ks][par] = 32768 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K >> 6;
+#define DMA(rs, src, dst, st, kt) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (st) * 65536 + dst), 16, src, (kt) * 128, 0, 0);
+#define GA(sub, st, kt) { DMA(rsA, srcA[sub][0], dstA[sub][0], st, kt) DMA(rsA, srcA[sub][1], dstA[sub][1], st, kt) }
+#define GW(sub, st, kt) { DMA(rsW, srcW[sub][0], dstW[sub][0], st, kt) DMA(rsW, srcW[sub][1], dstW[sub][1], st, kt) }
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define BAR __builtin_amdgcn_s_barrier();
+#define PINB __builtin_amdgcn_sched_barrier(0);
+#define LD_M(sb, a)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) \
+      fm[t][ks] = *(const vec8*)((sb) + offM[ks][t & 1] + ((a) * 2 + (t >> 1)) * 4096);
+#define LD_N(FN, sb, b)                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 2; ++t) \
+      FN[t][ks] = *(const vec8*)((sb) + offN[ks][t] + (b) * 4096);
+#define MM(FN, a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(FN[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+#define QUADX(FN, a, b)                                                                      \
+  {                                                                                          \
+    LGKM0                                                                                    \
+    PINB                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                           \
+    MM(FN, a, b, 0, 0, 0) MM(FN, a, b, 0, 1, 0) MM(FN, a, b, 1, 0, 0) MM(FN, a, b, 1, 1, 0)  \
+    MM(FN, a, b, 2, 0, 0) MM(FN, a, b, 2, 1, 0) MM(FN, a, b, 3, 0, 0) MM(FN, a, b, 3, 1, 0)  \
+    MM(FN, a, b, 0, 0, 1) MM(FN, a, b, 0, 1, 1) MM(FN, a, b, 1, 0, 1) MM(FN, a, b, 1, 1, 1)  \
+    MM(FN, a, b, 2, 0, 1) MM(FN, a, b, 2, 1, 1) MM(FN, a, b, 3, 0, 1) MM(FN, a, b, 3, 1, 1)  \
+    __builtin_amdgcn_s_setprio(0);                                                           \
+    PINB                                                                                     \
+  }
+// one K tile: FB0 holds B0(kt) on entry; FB1 receives B1(kt) and then B0(kt+1)
+#define KTILE(kt, FB0, FB1)                                                                   \
+  {                                                                                           \
+    const int cur = (kt) & 1, nxt = cur ^ 1;                                                  \
+    const bool more1 = (kt) + 1 < nk, more2 = (kt) + 2 < nk;                                  \
+    const char* sb = smem + cur * 65536;                                                      \
+    /* P0: confirm B1(kt); read A0(kt); issue A0(kt+1) */                                     \
+    if (more1) WAIT_VM(4); else WAIT_VM(2);                                                   \
+    LD_M(sb, 0)                                                                               \
+    if (more1) GA(0, nxt, (kt) + 1)                                                           \
+    BAR                                                                                       \
+    QUADX(FB0, 0, 0)                                                                          \
+    BAR                                                                                       \
+    /* P1: confirm A1(kt); read B1(kt); issue B1(kt+1) */                                     \
+    if (more1) WAIT_VM(4); else WAIT_VM(0);                                                   \
+    LD_N(FB1, sb, 1)                                                                          \
+    if (more1) GW(1, nxt, (kt) + 1)                                                           \
+    BAR                                                                                       \
+    QUADX(FB1, 0, 1)                                                                          \
+    BAR                                                                                       \
+    /* P2: confirm B0(kt+1); read A1(kt); issue A1(kt+1) */                                   \
+    if (more1) WAIT_VM(4);                                                                    \
+    LD_M(sb, 1)                                                                               \
+    if (more1) GA(1, nxt, (kt) + 1)                                                           \
+    BAR                                                                                       \
+    QUADX(FB1, 1, 1)                                                                          \
+    BAR                                                                                       \
+    /* P3: confirm A0(kt+1); read B0(kt+1) into the set B1 vacated; issue B0(kt+2) */         \
+    if (more1) WAIT_VM(4);                                                                    \
+    if (more1) LD_N(FB1, smem + nxt * 65536, 0)                                               \
+    if (more2) GW(0, cur, (kt) + 2)                                                           \
+    BAR                                                                                       \
+    QUADX(FB0, 1, 0)                                                                          \
+    BAR                                                                                       \
+  }
+
+  // prologue: B0, A0, B1, A1 of tile 0 and B0 of tile 1; B0(0) in registers, A0(0) confirmed
+  GW(0, 0, 0) GA(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
+  if (nk > 1) GW(0, 1, 1)
+  vec8 fm[4][2], fnX[2][2], fnY[2][2];
+  if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
+  BAR
+  LD_N(fnX, smem, 0)
+  if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
+  for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
+    KTILE(kt, fnX, fnY)
+    KTILE(kt + 1, fnY, fnX)
+  }
+  if (wr == 0) BAR   // balance the barrier count of the two groups
+#undef DMA
+#undef GA
+#undef GW
+#undef WAIT_VM
+#undef LGKM0
+#undef BAR
+#undef PINB
+#undef LD_M
+#undef LD_N
+#undef MM
+#undef QUADX
+#undef KTILE
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+}
+
 template <typename T>
 static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped) {
   const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
@@ -824,6 +1012,29 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
   const int total = patches_n * patches_m;
   const int grid = ((total + 7) / 8) * 8 * 8 * PN;
   dim3 g(grid), b(512);
+  if (overlapped >= 14 && ((p.K >> 6) & 1)) overlapped = 13;   // the two-set kernels need an even K-tile count
+  if (overlapped == 14 || (overlapped >= 30 && overlapped < 40)) {   // staggered, two N-side fragment sets
+    // 14: 8-row patches, no start stagger.  30 + 8*b + k: balanced patches if b, k start slots
+    int PMx = 8, stg = 1;
+    if (overlapped >= 30) {
+      const int code = overlapped - 30;
+      stg = (code & 7) + 1;
+      if (code >> 3) {   // smaller patches until every XCD gets >= 16 of them (even load across the 8 XCDs)
+        while (PMx > 1 && ((tiles_m + PMx - 1) / PMx) * patches_n < 128) PMx >>= 1;
+      }
+    }
+    const int pm_x = (tiles_m + PMx - 1) / PMx;
+    const int total_x = patches_n * pm_x;
+    dim3 gx(((total_x + 7) / 8) * 8 * PMx * PN);
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm16_256x_kernel<T, EPI_BIAS>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256x_kernel<T, EPI_BIAS_GELU>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256x_kernel<T, EPI_BIAS_RESID>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+      case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256x_kernel<T, EPI_ACT_F32>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+      case EPI_PATCH: hipLaunchKernelGGL((gemm16_256x_kernel<T, EPI_PATCH>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+    }
+    return;
+  }
   if (overlapped == 13) {   // staggered, both DMA issues in the load segment, buffer_load ... lds
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_BIAS, 2, 0, true>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -844,7 +1055,11 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
     }
     return;
   }
-  if (overlapped >= 5 && epi == EPI_ACT_F32) {   // timing ablations of the staggered kernel (GL = 2)
+  if (overlapped == 40 && epi == EPI_ACT_F32) {   // timing ablation: staggered kernel without epilogue stores
+    hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 8>), g, b, 0, s, p, PN, patches_n, total);
+    return;
+  }
+  if (overlapped >= 5 && overlapped <= 11 && epi == EPI_ACT_F32) {   // timing ablations of the staggered kernel (GL = 2)
     switch (overlapped) {
       case 5: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 1>), g, b, 0, s, p, PN, patches_n, total); break;
       case 6: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 2>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -852,11 +1067,12 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
       case 8: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 4>), g, b, 0, s, p, PN, patches_n, total); break;
       case 9: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 5>), g, b, 0, s, p, PN, patches_n, total); break;
       case 10: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 6>), g, b, 0, s, p, PN, patches_n, total); break;
-      default: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 7>), g, b, 0, s, p, PN, patches_n, total); break;
+      case 11: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 7>), g, b, 0, s, p, PN, patches_n, total); break;
+      default: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 8>), g, b, 0, s, p, PN, patches_n, total); break;
     }
     return;
   }
-  if (overlapped >= 5) overlapped = 4;
+  if (overlapped >= 5 && overlapped <= 11) overlapped = 4;
   if (overlapped >= 2) {   // staggered kernel, GL = overlapped - 2 DMA instructions in the load segment
 #define LV(E) { if (overlapped == 2) hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 0>), g, b, 0, s, p, PN, patches_n, total); \
                else if (overlapped == 3) hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 1>), g, b, 0, s, p, PN, patches_n, total); \

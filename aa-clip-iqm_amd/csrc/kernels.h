@@ -30,6 +30,7 @@ bool gemm256_applicable(int dtype, const GemmParams& p);
 void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined);
 void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped);
 void set_gemm_variant(int v);
+void set_tail_peel(int v);
 void read_gemm_stamps(double* out3, int nwaves);
 void set_attn_variant(int v);
 

@@ -194,7 +194,7 @@ def main():
             "whole_path_tflops": round(value * gflop_img / 1e3, 1),
             "whole_path_frac_of_mfma_peak": round(value * gflop_img / 1e3 / (peak * n_gpus), 4),
             "roofline": {
-                "kernel": "gemm16_256v_kernel<f16, EPI_BIAS_GELU> (mlp.c_fc, M=B*1370, N=4096, K=1024)",
+                "kernel": "gemm16_256x_kernel<f16, EPI_BIAS_GELU> (mlp.c_fc, M=B*1370, N=4096, K=1024)",
                 "bound": "mfma",
                 "achieved": round(achieved, 1),
                 "peak": peak,

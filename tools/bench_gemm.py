@@ -22,10 +22,12 @@ M = a.batch * 1370
 shapes = [("qkv", _lib.EPI_BIAS, 3072, 1024), ("out_proj", _lib.EPI_BIAS_RESID, 1024, 1024),
           ("c_fc", _lib.EPI_BIAS_GELU, 4096, 1024), ("c_proj", _lib.EPI_BIAS_RESID, 1024, 4096),
           ("adapter", _lib.EPI_ACT_F32, 1024, 1024), ("seg_proj", _lib.EPI_ACT_F32, 768, 1024),
-          ("k4096_f32out", _lib.EPI_ACT_F32, 1024, 4096), ("n4096_f32out", _lib.EPI_ACT_F32, 4096, 1024)]
+          ("k4096_f32out", _lib.EPI_ACT_F32, 1024, 4096), ("n4096_f32out", _lib.EPI_ACT_F32, 4096, 1024),
+          ("k64_n4096", _lib.EPI_ACT_F32, 4096, 64), ("k128_n4096", _lib.EPI_ACT_F32, 4096, 128),
+          ("k256_n4096", _lib.EPI_ACT_F32, 4096, 256)]
 if a.only:
     shapes = [s for s in shapes if s[0] in a.only.split(",")]
-if any(v in (4, 5, 11, 12, 13, 14, 15, 16) for v in [int(v) for v in a.variants.split(",")]):
+if any(v in (4, 5, 11, 12, 13, 14, 15, 16, 46) for v in [int(v) for v in a.variants.split(",")]):
     shapes = [s for s in shapes if s[1] == _lib.EPI_ACT_F32]   # timing ablations exist for the fp32-out epilogue only
 variants = [int(v) for v in a.variants.split(",")]
 st = torch.cuda.current_stream().cuda_stream
