@@ -553,6 +553,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
 #define DC1(X) if (GL < 2) { X }
 
   // prologue: tile 0 in consumption order plus A0 of tile 1; A0,B0(0) confirmed by everyone
+  unsigned long long t_setup = 0;
+  if (ABL == 7) t_setup = stamp();
   GA(0, 0, 0) GW(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
   if (nk > 1) GA(0, 1, 1)
   if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
                  NO_BAR = ABL == 4 || ABL == 6;
   constexpr bool STAMP = ABL == 7;
   unsigned long long tl = 0, tc = 0, tb = 0, t_prev = 0, t_a = 0, t_b = 0, tw = 0, tr = 0, tg = 0;
-  if (STAMP) { t_prev = stamp(); tw = t_prev - t_entry; }
+  if (STAMP) { t_prev = stamp(); tw = t_prev - t_entry; tg = t_setup - t_entry; }
   if (NO_LDS) { LD_M(smem, 0) LD_N(smem, 0) }
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;

@@ -11,7 +11,8 @@ lib.aaclip_debug_gemm_stamps.argtypes = [C.POINTER(C.c_double), C.c_int]
 dev = torch.device("cuda:0")
 import sys as _s
 K = int(_s.argv[1]) if len(_s.argv) > 1 else 4096
-M, N = 64 * 1370, 1024
+N = int(_s.argv[2]) if len(_s.argv) > 2 else 1024
+M = 64 * 1370
 A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) * K ** -0.5).half()
 out = torch.zeros(M, N, device=dev)
 st = torch.cuda.current_stream().cuda_stream
@@ -23,5 +24,6 @@ for v in (17,):
     o = (C.c_double * 6)()
     lib.aaclip_debug_gemm_stamps(o, 16384)
     nk = K // 64
+    print(f"entry -> address setup done (before first DMA): {o[5]:.0f} cycles")
     print(f"per tile per wave (cycles): entry->K loop {o[3]:.0f}   K loop {(o[0]+o[1]+o[2]):.0f}   epilogue incl. store drain {o[4]:.0f}")
     print(f"per K tile per wave (cycles): load+barrier {o[0]/nk:.0f}  compute {o[1]/nk:.0f}  barrier-after-compute {o[2]/nk:.0f}  total {(o[0]+o[1]+o[2])/nk:.0f}  (4 phases per K tile; MFMA own time 4 x 256 = 1024)")
