@@ -39,6 +39,9 @@ SIGNATURES = {
     "aaclip_anomaly_map": (_i, [C.POINTER(_vp), _i, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "aaclip_similarity_map_train": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "aaclip_text_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "aaclip_resample_ksize": (_i, [_i, _i]),
+    "aaclip_resample_table": (_i, [_i, _i, _vp, _vp]),
+    "aaclip_preprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aaclip_row_head": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _sz, _vp]),
     "aaclip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _i, _f, _vp]),
     "aaclip_gemm": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),

@@ -331,3 +331,56 @@ def similarity_map_train(seg: torch.Tensor, text_feature: torch.Tensor, img_size
                                                img_size, ws.data_ptr(), ws.numel(), _stream(out.device)),
                "similarity_map_train")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# image pre-processing (reference dataset/__init__.py:150-161), Pillow-exact on the GPU
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def resample_table(in_size: int, out_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host tables of one resize axis: bounds int32 [out,2], coefs int32 [out,ksize] (library-built)."""
+    lib = _lib.load()
+    k = lib.aaclip_resample_ksize(int(in_size), int(out_size))
+    if k < 1:
+        _lib.check(k, "resample_ksize")
+    bounds = torch.empty(out_size, 2, dtype=torch.int32)
+    coefs = torch.empty(out_size, k, dtype=torch.int32)
+    _lib.check(lib.aaclip_resample_table(int(in_size), int(out_size), bounds.data_ptr(), coefs.data_ptr()),
+               "resample_table")
+    return bounds, coefs
+
+
+_PRE_TABLES: Dict[tuple, tuple] = {}
+
+
+def _normalise_lut(mean, std) -> torch.Tensor:
+    # the fp32 operations of ToTensor (.div(255)) and Normalize (.sub_(mean).div_(std)), for every byte value
+    v = torch.arange(256, dtype=torch.float32).div(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(-1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(-1, 1)
+    return (v.unsqueeze(0).repeat(3, 1).sub_(m).div_(s)).contiguous()
+
+
+def preprocess(src_u8: torch.Tensor, img_size: int, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """uint8 [B,Hs,Ws,3] (HWC, on the GPU) -> fp32 [B,3,S,S]: BICUBIC resize, ToTensor, Normalize."""
+    require_gpu(src_u8, "preprocess")
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[-1] != 3:
+        raise ValueError("preprocess expects uint8 [B, H, W, 3]")
+    src_u8 = src_u8.contiguous()
+    B, Hs, Ws, _ = src_u8.shape
+    dev = src_u8.device
+    key = (dev, Hs, Ws, img_size, tuple(mean), tuple(std))
+    tabs = _PRE_TABLES.get(key)
+    if tabs is None:
+        hb, hk = resample_table(Ws, img_size)
+        vb, vk = resample_table(Hs, img_size)
+        tabs = tuple(t.to(dev) for t in (hb, hk, vb, vk, _normalise_lut(mean, std)))
+        _PRE_TABLES[key] = tabs
+    hb, hk, vb, vk, lut = tabs
+    out = torch.empty(B, 3, img_size, img_size, device=dev, dtype=torch.float32)
+    _lib.check(_lib.load().aaclip_preprocess(src_u8.data_ptr(), B, Hs, Ws, img_size, hb.data_ptr(), hk.data_ptr(),
+                                             vb.data_ptr(), vk.data_ptr(), lut.data_ptr(), out.data_ptr(),
+                                             _stream(dev)), "preprocess")
+    return out

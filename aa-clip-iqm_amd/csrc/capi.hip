@@ -340,6 +340,36 @@ int aaclip_similarity_map_train(const float* seg, const float* anchors, long anc
   return finish("similarity_map_train");
 }
 
+int aaclip_resample_ksize(int in_size, int out_size) {
+  if (in_size < 1 || out_size < 1) return fail(-1, "resample_ksize: sizes must be positive");
+  return resample_ksize(in_size, out_size);
+}
+
+int aaclip_resample_table(int in_size, int out_size, int32_t* bounds, int32_t* coefs) {
+  REQUIRE(bounds && coefs, "resample_table: null pointer");
+  REQUIRE(in_size >= 1 && out_size >= 1 && in_size <= (1 << 16) && out_size <= (1 << 16),
+          "resample_table: sizes must be 1..65536");
+  resample_table(in_size, out_size, bounds, coefs);
+  return 0;
+}
+
+int aaclip_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const int32_t* hbounds, const int32_t* hcoefs,
+                      const int32_t* vbounds, const int32_t* vcoefs, const float* lut, float* out, void* stream) {
+  REQUIRE(src && hbounds && hcoefs && vbounds && vcoefs && lut && out, "preprocess: null pointer");
+  REQUIRE(B > 0 && B <= 65535 && Hs >= 1 && Ws >= 1 && Hs <= (1 << 16) && Ws <= (1 << 16), "preprocess: bad source shape");
+  REQUIRE(S >= 1 && S <= 4096, "preprocess: output size must be 1..4096");
+  // largest tile height whose horizontally resampled rows fit in LDS (64 columns x 3 planes x rows bytes)
+  int ty = 16, rows = 0;
+  for (; ty >= 1; ty >>= 1) {
+    rows = preprocess_tile_rows(Hs, S, ty);
+    if ((size_t)3 * rows * 64 <= 60 * 1024) break;
+  }
+  REQUIRE(ty >= 1, "preprocess: source too tall for one output row to fit in LDS (scale > ~60)");
+  launch_preprocess(src, B, Hs, Ws, S, hbounds, hcoefs, resample_ksize(Ws, S), vbounds, vcoefs, resample_ksize(Hs, S),
+                    ty, rows, lut, out, (hipStream_t)stream);
+  return finish("preprocess");
+}
+
 int aaclip_text_embed(const int32_t* tokens, const float* table, const float* pos, float* x, int n, int T, int D,
                       int vocab, void* stream) {
   REQUIRE(tokens && table && pos && x, "text_embed: null pointer");

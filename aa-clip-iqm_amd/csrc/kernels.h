@@ -64,4 +64,12 @@ void launch_blur_upsample(const float* pre, float* out, int B, int g, int S, int
 void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int S, hipStream_t s);
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
 
+// ---- preprocess.hip : 8-bit bicubic resize + ToTensor + Normalize (Pillow-exact)
+int resample_ksize(int in_size, int out_size);
+void resample_table(int in_size, int out_size, int32_t* bounds, int32_t* coefs);   // host buffers
+int preprocess_tile_rows(int in_size, int out_size, int ty);
+void launch_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const int32_t* hb, const int32_t* hk, int kx,
+                       const int32_t* vb, const int32_t* vk, int ky, int TY, int lds_rows, const float* lut,
+                       float* out, hipStream_t s);
+
 }  // namespace aaclip

@@ -110,6 +110,21 @@ int aaclip_anomaly_map(const float* const* seg, int NL, const float* anchors, lo
 int aaclip_similarity_map_train(const float* seg, const float* anchors, long anchor_bstride, float* out, int B, int g,
                                 int E, int S, void* ws, size_t ws_bytes, void* stream);
 
+/* Image pre-processing in front of the patch embed: Pillow's 8-bit BICUBIC resize to S x S,
+ * ToTensor (v/255) and Normalize((v - mean)/std), bit-exact.  Replaces the reference's
+ * dataset transform (reference dataset/__init__.py:150-161 and :62-71: transforms.Resize(
+ * (S,S), Image.BICUBIC) -> ToTensor -> Normalize), which runs in the DataLoader workers on CPU.
+ *   aaclip_resample_ksize / aaclip_resample_table are HOST functions: they fill host buffers
+ *   bounds[2*out] (first source index, tap count) and coefs[out*ksize] (22-bit fixed point) with
+ *   Pillow's weights for one axis; the caller uploads them once per (source size, S).
+ *   aaclip_preprocess: src uint8 [B,Hs,Ws,3] (HWC, device), tables for the horizontal (Ws -> S)
+ *   and vertical (Hs -> S) pass (device), lut fp32 [3,256] = normalised value of every byte per
+ *   channel (device), out fp32 [B,3,S,S]. */
+int aaclip_resample_ksize(int in_size, int out_size);
+int aaclip_resample_table(int in_size, int out_size, int32_t* bounds, int32_t* coefs);
+int aaclip_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const int32_t* hbounds, const int32_t* hcoefs,
+                      const int32_t* vbounds, const int32_t* vcoefs, const float* lut, float* out, void* stream);
+
 /* Text embedding: x[i*T+t] = token_embedding[tokens[i,t]] + positional_embedding[t].
  * Replaces reference model/adapter.py:277-281 (model/model.py:192-194). */
 int aaclip_text_embed(const int32_t* tokens, const float* table, const float* pos, float* x, int n, int T, int D,

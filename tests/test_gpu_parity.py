@@ -419,3 +419,40 @@ def test_auroc_parity_on_synthetic_masks(dev, full_weights):
     r2 = FU.metrics_eval(masks, labels, omap.numpy(), oscore.numpy(), "synthetic", "Industrial")
     for k in ("pixel AUC", "pixel AP"):
         assert abs(r1[k] - r2[k]) <= 0.1 + 1e-9, (k, r1, r2)   # values are percentages rounded to 2 decimals
+
+
+# ----------------------------------------------------------------------------
+# image pre-processing (bit-exact: integer resampling + table normalisation)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,s,B", [(96, 96, 70, 2), (150, 130, 70, 3), (40, 56, 70, 1), (70, 70, 70, 2),
+                                     (70, 100, 70, 1), (301, 70, 70, 1), (700, 700, 518, 2), (1024, 1024, 518, 2),
+                                     (256, 300, 518, 1), (2500, 900, 518, 1), (5, 3, 70, 1)])
+def test_preprocess_bit_exact(dev, h, w, s, B):
+    from oracle import preprocess_oracle as P
+    rng = np.random.default_rng(h * 31 + w)
+    imgs = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    imgs[0, : max(h // 3, 1), : max(w // 3, 1)] = 255          # saturated block: negative lobes clip
+    got = engine.preprocess(T(imgs).to(dev), s).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], P.preprocess(imgs[b], s)), f"image {b} differs from the oracle"
+
+
+def test_preprocess_matches_golden_and_pillow(dev):
+    from PIL import Image
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "preprocess.npz"))
+    for i, (h, w, s) in enumerate(g["cases"]):
+        got = engine.preprocess(T(g[f"in{i}"][None]).to(dev), int(s)).cpu().numpy()[0]
+        assert np.array_equal(got, g[f"f32_{i}"]), f"golden case {i}"
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (333, 417, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img).resize((518, 518), Image.BICUBIC))
+    lut = engine._normalise_lut(engine.CLIP_MEAN, engine.CLIP_STD).numpy()
+    want = np.stack([lut[c][ref[..., c]] for c in range(3)])
+    assert np.array_equal(engine.preprocess(T(img[None]).to(dev), 518).cpu().numpy()[0], want)
+
+
+def test_preprocess_rejects_bad_input(dev):
+    with pytest.raises(ValueError):
+        engine.preprocess(torch.zeros(1, 8, 8, 4, dtype=torch.uint8, device=dev), 70)
+    with pytest.raises(RuntimeError):
+        engine.preprocess(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), 70)
