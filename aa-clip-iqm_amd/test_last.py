@@ -1,0 +1,157 @@
+"""Evaluation harness on the MI355X path, with the reference script's entry points
+(reference test_last.py:53-158 get_predictions, :160-336 main): per class, images -> anomaly maps
+and image scores -> pixel / image AUROC and AP -> a table with an "Average" row.
+
+Differences from the reference, all on purpose:
+  * the four per-level maps and their sum come from ONE fused kernel (calculate_anomaly_map);
+  * the image score is the intended (det_b . t_abnormal + 1)/2 (the reference's broadcast
+    quirk is documented in DESIGN.md);
+  * the IQM branch is not built, so maps are the text-only branch (test_last.py:148-149);
+  * checkpoints are read with weights_only=True;
+  * `--device_preprocess` moves resize + normalise onto the GPU (bit-identical to the CPU transform).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+from glob import glob
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from aaclip_hip import engine
+from dataset import DOMAINS, get_dataset
+from forward_utils import calculate_anomaly_map, get_adapted_text_embedding, image_score, metrics_eval
+from model.adapter import AdaptedCLIP
+from model.clip import create_model
+
+NUMERIC_COLS = ["pixel AUC", "pixel AP", "image AUC", "image AP"]
+
+
+def setup_seed(seed: int) -> None:
+    import random
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def get_predictions(model, class_text_embeddings: torch.Tensor, test_loader, device, img_size: int,
+                    dataset: str = "MVTec"):
+    """-> (masks [N,1,S,S], labels [N], preds [N,S,S], preds_image [N], file_names) like
+    reference test_last.py:53-158 (text-only branch)."""
+    masks, labels, preds, preds_image, file_names = [], [], [], [], []
+    domain = DOMAINS[dataset]
+    for input_data in test_loader:
+        image = input_data["image"].to(device, non_blocking=True)
+        class_name = input_data["class_name"]
+        assert len(set(class_name)) == 1, "mixed class not supported"
+        masks.append(np.asarray(input_data["mask"].cpu().numpy()))
+        labels.append(np.asarray(torch.as_tensor(input_data["label"]).cpu().numpy()))
+        file_names.extend(input_data["file_name"])
+        if image.dtype == torch.uint8:                       # raw HWC frames: resize + normalise on the GPU
+            image = engine.preprocess(image, img_size)
+        patch_features, det_feature, _ = model(image, text_embeddings=None)
+        preds_image.append(image_score(det_feature, class_text_embeddings).cpu().numpy())
+        preds.append(calculate_anomaly_map(patch_features, class_text_embeddings, img_size, domain=domain).cpu().numpy())
+    return (np.concatenate(masks, axis=0), np.concatenate(labels, axis=0), np.concatenate(preds, axis=0),
+            np.concatenate(preds_image, axis=0), file_names)
+
+
+def evaluate(model, image_datasets: Dict[str, torch.utils.data.Dataset], text_embeddings: Dict[str, torch.Tensor],
+             device, img_size: int, dataset: str, batch_size: int = 32, loader_kwargs=None, logger=None) -> List[dict]:
+    """The per-class loop of reference test_last.py:282-326; returns the result rows, last row = Average."""
+    rows = []
+    for class_name, image_dataset in image_datasets.items():
+        loader = torch.utils.data.DataLoader(image_dataset, batch_size=batch_size, shuffle=False, **(loader_kwargs or {}))
+        with torch.no_grad():
+            masks, labels, preds, preds_image, _ = get_predictions(
+                model=model, class_text_embeddings=text_embeddings[class_name], test_loader=loader, device=device,
+                img_size=img_size, dataset=dataset)
+        rows.append(metrics_eval(masks, labels, preds, preds_image, class_name, domain=DOMAINS[dataset]))
+        if logger:
+            logger.info("%s", rows[-1])
+    avg = {c: float(np.mean([r[c] for r in rows])) for c in NUMERIC_COLS}
+    avg["class name"] = "Average"
+    rows.append(avg)
+    return rows
+
+
+def format_table(rows: List[dict]) -> str:
+    cols = ["class name"] + NUMERIC_COLS
+    lines = ["  ".join(f"{c:>14s}" for c in cols)]
+    for r in rows:
+        lines.append("  ".join(f"{r[c]:>14s}" if isinstance(r[c], str) else f"{r[c]:>14.2f}" for c in cols))
+    return "\n".join(lines)
+
+
+def load_adapters(model: AdaptedCLIP, save_path: str, logger=None) -> bool:
+    """reference test_last.py:230-251: optional text adapter, newest image adapter (by epoch number)."""
+    text_file = glob(os.path.join(save_path, "text_adapter.pth"))
+    adapt_text = len(text_file) > 0
+    if adapt_text:
+        ckpt = torch.load(text_file[0], map_location="cpu", weights_only=True)
+        model.text_adapter.load_state_dict(ckpt["text_adapter"])
+    files = glob(os.path.join(save_path, "image_adapter_*.pth"))
+    assert len(files) > 0, "image adapter checkpoint not found"
+    files = sorted(files, key=lambda x: int(x.split("_")[-1].split(".")[0]))
+    ckpt = torch.load(files[-1], map_location="cpu", weights_only=True)
+    model.image_adapter.load_state_dict(ckpt["image_adapter"])
+    if logger:
+        logger.info("load model from epoch %s", ckpt.get("epoch"))
+    return adapt_text
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="AA-CLIP evaluation on MI355X")
+    parser.add_argument("--model_name", type=str, default="ViT-L-14-336")
+    parser.add_argument("--img_size", type=int, default=518)
+    parser.add_argument("--relu", action="store_true")
+    parser.add_argument("--dataset", type=str, default="MVTec")
+    parser.add_argument("--shot", type=int, default=4)
+    parser.add_argument("--batch_size", type=int, default=32)
+    parser.add_argument("--image_batch_size", type=int, default=32)
+    parser.add_argument("--seed", type=int, default=111)
+    parser.add_argument("--save_path", type=str, default="ckpt/baseline")
+    parser.add_argument("--text_adapt_weight", type=float, default=0.1)
+    parser.add_argument("--image_adapt_weight", type=float, default=0.1)
+    parser.add_argument("--text_adapt_until", type=int, default=3)
+    parser.add_argument("--image_adapt_until", type=int, default=6)
+    parser.add_argument("--precision", type=str, default="fp16", help="fp32 (exact), fp16 or bf16 matrix products")
+    parser.add_argument("--device_preprocess", action="store_true", help="resize + normalise on the GPU")
+    args = parser.parse_args(argv)
+
+    setup_seed(args.seed)
+    os.makedirs(args.save_path, exist_ok=True)
+    logger = logging.getLogger(__name__)
+    logging.basicConfig(filename=os.path.join(args.save_path, "test.log"), encoding="utf-8", level=logging.INFO)
+    logger.info("args: %s", vars(args))
+    if not torch.cuda.is_available():
+        raise RuntimeError("the AA-CLIP HIP path needs an MI355X; there is no CPU fallback")
+    device = torch.device("cuda:0")
+    clip_model = create_model(model_name=args.model_name, img_size=args.img_size, device=device, pretrained="openai",
+                              require_pretrained=True, precision=args.precision)
+    clip_model.eval()
+    model = AdaptedCLIP(clip_model=clip_model, text_adapt_weight=args.text_adapt_weight,
+                        image_adapt_weight=args.image_adapt_weight, text_adapt_until=args.text_adapt_until,
+                        image_adapt_until=args.image_adapt_until, relu=args.relu).to(device)
+    model.eval()
+    adapt_text = load_adapters(model, args.save_path, logger)
+    image_datasets = get_dataset(args.dataset, args.img_size, None, args.shot, "test", logger=logger,
+                                 device_preprocess=args.device_preprocess)
+    with torch.no_grad():
+        text_embeddings = get_adapted_text_embedding(model if adapt_text else clip_model, args.dataset, device)
+    rows = evaluate(model, image_datasets, text_embeddings, device, args.img_size, args.dataset,
+                    batch_size=args.image_batch_size, loader_kwargs={"num_workers": 4, "pin_memory": True},
+                    logger=logger)
+    table = format_table(rows)
+    logger.info("final results:\n%s", table)
+    print(table)
+    return rows
+
+
+if __name__ == "__main__":
+    main()

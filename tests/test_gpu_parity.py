@@ -456,3 +456,52 @@ def test_preprocess_rejects_bad_input(dev):
         engine.preprocess(torch.zeros(1, 8, 8, 4, dtype=torch.uint8, device=dev), 70)
     with pytest.raises(RuntimeError):
         engine.preprocess(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), 70)
+
+
+# ----------------------------------------------------------------------------
+# evaluation harness end to end on a synthetic MVTec-style tree (test_last.get_predictions/evaluate)
+# ----------------------------------------------------------------------------
+def test_harness_end_to_end_vs_oracle(dev, tmp_path):
+    import dataset as D
+    import forward_utils as FU
+    import test_last as TL
+    from oracle import preprocess_oracle as P
+    from synth_dataset import write_tree
+    root = write_tree(str(tmp_path / "MVTec"))
+    meta = str(tmp_path / "meta" / "MVTec" / "full-shot.jsonl")
+    D.build_metadata(root, meta)
+    cfg, sd, ia, ta, clip, model = build_tiny(dev, "fp32")
+    S = cfg.image_size
+    classes = ["bottle", "grid"]
+    with torch.no_grad():
+        anchors = {c: FU.get_adapted_single_class_text_embedding(model, "MVTec", c, dev) for c in classes}
+    host = {c: D.BaseSingleClassDataset(root, meta, S, c) for c in classes}
+    raw = {c: D.BaseSingleClassDataset(root, meta, S, c, device_preprocess=True) for c in classes}
+    rows_host = TL.evaluate(model, host, anchors, dev, S, "MVTec", batch_size=4)
+    rows_raw = TL.evaluate(model, raw, anchors, dev, S, "MVTec", batch_size=4)
+    assert rows_host == rows_raw, "GPU pre-processing must give the very same table as the CPU transform"
+    assert rows_host[-1]["class name"] == "Average" and len(rows_host) == 3
+
+    # the same loop on the oracle
+    for c, row in zip(classes, rows_host):
+        ds = host[c]
+        imgs = torch.stack([ds[i]["image"] for i in range(len(ds))])
+        masks = np.stack([ds[i]["mask"].numpy() for i in range(len(ds))])
+        labels = np.array([ds[i]["label"] for i in range(len(ds))])
+        oseg, odet = O.adapted_visual_forward(imgs, sd, ia, cfg.vision.heads, image_adapt_until=2, levels=(2, 3))
+        sent = FU.class_sentences("MVTec", c)
+        from model.tokenizer import tokenize
+        cols = [O.adapted_encode_text(tokenize(s), sd, ta, cfg.text.heads, text_adapt_until=1) for s in sent]
+        oanch = O.class_anchor(cols[0], cols[1])
+        assert_close(anchors[c], oanch, 2e-4, 1e-3, f"{c} anchors")
+        omap = O.anomaly_map(oseg, oanch, S, "Industrial")
+        oscore = O.image_score(odet, oanch)
+        with torch.no_grad():
+            loader = torch.utils.data.DataLoader(ds, batch_size=4)
+            m2, l2, preds, preds_image, names = TL.get_predictions(model, anchors[c], loader, dev, S, "MVTec")
+        assert np.array_equal(m2, masks) and np.array_equal(l2, labels) and len(names) == len(ds)
+        assert_close(T(preds), omap, 2e-3, 1e-3, f"{c} maps (x100 cosines, fp32 path)")
+        assert_close(T(preds_image), oscore, 2e-4, 1e-3, f"{c} image scores")
+        want = FU.metrics_eval(masks, labels, omap.numpy(), oscore.numpy(), c, "Industrial")
+        for k in ("pixel AUC", "pixel AP"):
+            assert abs(row[k] - want[k]) <= 0.1 + 1e-9, (c, k, row, want)
