@@ -180,9 +180,18 @@ def patch_embed(img: torch.Tensor, visual, code: int) -> Tuple[torch.Tensor, int
     return x, B, L
 
 
+ATTN_FULL, ATTN_CAUSAL, ATTN_VV_BATCH = 0, 1, 2
+
+
 def run_block(x: torch.Tensor, block, B: int, L: int, heads: int, code: int, causal: bool = False,
               adapter_weight: Optional[torch.Tensor] = None, mix: float = 0.0) -> None:
-    """In place on x [B*L, D]: reference model/transformer.py:239-258 (+ adapter.py:163-170)."""
+    """In place on x [B*L, D]: reference model/transformer.py:239-258 (+ adapter.py:163-170).
+    A block flagged by VisionTransformer.DAPM_replace (`block.surgery`) runs the V-V attention over
+    the batch axis (reference transformer.py:102-152 as executed, include/aaclip.h AACLIP_ATTN_VV_BATCH)."""
+    if getattr(block, "surgery", False):
+        if causal:
+            raise ValueError("the V-V attention block takes no mask")
+        causal = ATTN_VV_BATCH
     require_gpu(x, "block")
     lib = _lib.load()
     D = x.shape[1]

@@ -183,9 +183,11 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
   return finish("patch_embed");
 }
 
-int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int causal,
+int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int attn_mode,
                  int dtype, void* ws, size_t ws_bytes, void* stream) {
   REQUIRE(dtype_ok(dtype), "block: bad dtype");
+  REQUIRE(attn_mode >= AACLIP_ATTN_FULL && attn_mode <= AACLIP_ATTN_VV_BATCH, "block: attn_mode must be 0, 1 or 2");
+  REQUIRE(attn_mode != AACLIP_ATTN_VV_BATCH || F >= 4 * D, "block: V-V attention needs F >= 4*D workspace columns");
   REQUIRE(x && w && ws, "block: null pointer");
   REQUIRE(w->ln1_w && w->ln1_b && w->qkv_w && w->qkv_b && w->out_w && w->out_b && w->ln2_w && w->ln2_b && w->fc_w &&
               w->fc_b && w->proj_w && w->proj_b,
@@ -209,14 +211,31 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
   // x += out_proj(attn(ln_1 x))
   { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
   memset(&p, 0, sizeof(p));
-  p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
   // 16-bit path: fold log2(e) into the q scale (one rounding) so the attention kernel works in log2 units
   const int log2q = dtype != AACLIP_F32;
-  p.ldc = 3 * D; p.scale_cols = D; p.scale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
-  { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
-  { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, causal, log2q, s); }
+  const float qscale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
+  const char* ctx = narrow;
+  if (attn_mode == AACLIP_ATTN_VV_BATCH) {
+    // only the value third of in_proj is needed; v lives behind the packed q|k|v buffer inside `big`
+    char* vbuf = big + (size_t)rows * 3 * D * es;
+    p.A = narrow; p.lda = D; p.W = (const char*)w->qkv_w + (size_t)2 * D * D * es; p.M = M; p.N = D; p.K = D;
+    p.bias = w->qkv_b + 2 * D; p.out = vbuf; p.ldc = D;
+    { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
+    {
+      ProfScope ps(2, s);
+      launch_vv_spread(dtype, vbuf, big, B, L, D, qscale, s);
+      launch_attention(dtype, big, narrow, /*batches=*/L, /*sequence=*/B, H, 0, log2q, s);
+      launch_vv_regroup(dtype, narrow, vbuf, B, L, D, s);
+    }
+    ctx = vbuf;
+  } else {
+    p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
+    p.ldc = 3 * D; p.scale_cols = D; p.scale = qscale;
+    { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
+    { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s); }
+  }
   memset(&p, 0, sizeof(p));
-  p.A = narrow; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
+  p.A = ctx; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
   { ProfScope ps(3, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
   // x += c_proj(gelu(c_fc(ln_2 x)))
   { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s); }

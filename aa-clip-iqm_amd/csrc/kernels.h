@@ -63,6 +63,9 @@ void launch_blur_upsample(const float* pre, float* out, int B, int g, int S, int
                           hipStream_t s);
 void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int S, hipStream_t s);
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
+// V-V "surgery" attention over the batch axis: regroup v [B*L,D] -> packed q|k|v rows l*B+b and back
+void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s);
+void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s);
 
 // ---- preprocess.hip : 8-bit bicubic resize + ToTensor + Normalize (Pillow-exact)
 int resample_ksize(int in_size, int out_size);

@@ -318,3 +318,70 @@ void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_
     hipLaunchKernelGGL(cast_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, src, (float*)dst, n4);
 }
 }  // namespace aaclip
+
+namespace aaclip {
+// ---- "surgery" (V-V) attention over the batch axis, reference model/transformer.py:102-152 as it
+// runs after DAPM_replace (the module unpacks the LND stream as [B,N,C]).
+// The attention kernels walk rows batch*L + pos; here the "sequence" is the image index b and the
+// "batch" is the token position l, so the value projection v [B*L, D] is regrouped into a packed
+// q|k|v buffer with rows l*B + b: q = v * scale (the score scale the QKV epilogue would have folded
+// into q), k = v, v = v.  4 elements per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void vv_spread_kernel(const T* __restrict__ v, T* __restrict__ qkv, int B, int L,
+                                                        int D, float scale) {
+  const long n4 = (long)B * L * D / 4;
+  const int d4 = D / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const int b = (int)(r / L), l = (int)(r % L);
+    const T* src = v + r * D + c;
+    T* dst = qkv + ((long)l * B + b) * 3 * D + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const T val = src[j];
+      dst[j] = from_float<T>(to_float<T>(val) * scale);
+      dst[D + j] = val;
+      dst[2 * D + j] = val;
+    }
+  }
+}
+// ctx rows l*B + b -> rows b*L + l
+template <typename T>
+__global__ __launch_bounds__(256) void vv_regroup_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int L,
+                                                         int D) {
+  const long n4 = (long)B * L * D / 4;
+  const int d4 = D / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const int b = (int)(r / L), l = (int)(r % L);
+    const T* s4 = src + ((long)l * B + b) * D + c;
+    T* d4p = dst + r * D + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d4p[j] = s4[j];
+  }
+}
+static unsigned vv_blocks(long n4) {
+  long blocks = (n4 + 255) / 256;
+  return (unsigned)(blocks > 16384 ? 16384 : blocks);
+}
+void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s) {
+  const unsigned g = vv_blocks((long)B * L * D / 4);
+  if (dtype == AACLIP_F16)
+    hipLaunchKernelGGL(vv_spread_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)v, (f16*)qkv, B, L, D, scale);
+  else if (dtype == AACLIP_BF16)
+    hipLaunchKernelGGL(vv_spread_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)v, (bf16*)qkv, B, L, D, scale);
+  else
+    hipLaunchKernelGGL(vv_spread_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)v, (float*)qkv, B, L, D, scale);
+}
+void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s) {
+  const unsigned g = vv_blocks((long)B * L * D / 4);
+  if (dtype == AACLIP_F16)
+    hipLaunchKernelGGL(vv_regroup_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)src, (f16*)dst, B, L, D);
+  else if (dtype == AACLIP_BF16)
+    hipLaunchKernelGGL(vv_regroup_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, B, L, D);
+  else
+    hipLaunchKernelGGL(vv_regroup_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, B, L, D);
+}
+}  // namespace aaclip

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import re
 from copy import deepcopy
 from pathlib import Path
@@ -49,7 +50,14 @@ def get_model_config(model_name):
 
 def load_state_dict(checkpoint_path: str, map_location="cpu"):
     """reference model/clip.py:62-70; only weights are unpickled."""
-    ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=True)
+    try:
+        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=True)
+    except RuntimeError as e:
+        if "TorchScript" not in str(e):
+            raise
+        # OpenAI's released .pt files are TorchScript archives (reference model/openai.py:56-60 tries
+        # torch.jit.load first); only the parameters are taken from it.
+        ckpt = torch.jit.load(checkpoint_path, map_location="cpu").eval().state_dict()
     sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
     if next(iter(sd.items()))[0].startswith("module"):
         sd = {k[7:]: v for k, v in sd.items()}
@@ -93,7 +101,7 @@ def create_model(model_name: str, img_size: int, pretrained: Optional[str] = Non
         cfg["vision_cfg"]["image_size"] = force_image_size   # reference clip.py:159-161 (img_size ignored here)
     model = CLIP(**cfg, cast_dtype=get_cast_dtype(precision), precision=precision)
     if pretrained:
-        path = _MODEL_CKPT_PATHS.get(model_name)
+        path = os.environ.get("AACLIP_CLIP_CKPT") or _MODEL_CKPT_PATHS.get(model_name)
         if not path or not Path(path).exists():
             raise RuntimeError(f"Model {model_name} not found; expected a local checkpoint at {path}")
         logging.info("Loading pretrained %s weights from %s", model_name, path)

@@ -180,10 +180,16 @@ class VisionTransformer(nn.Module):
         self.global_average_pool = False
         self.attn_pool = None
 
+    @torch.no_grad()
     def DAPM_replace(self, DPAM_layer):
-        raise NotImplementedError(
-            "V-V 'surgery' attention (reference transformer.py:102-152,406-425) is training-stage-1 only and "
-            "outside the inference hot path (SURVEY.md 8(f) F3)")
+        """reference transformer.py:406-425: the last DPAM_layer-1 blocks get the V-V "surgery"
+        attention (:102-152) with the block's own in_proj/out_proj weights.  No module is swapped
+        here: the block is flagged and aaclip_block runs AACLIP_ATTN_VV_BATCH, which reproduces what
+        the reference executes -- attention over the batch axis per token position (SURVEY.md 8(f)
+        F3), so features depend on which images share a batch, exactly as in the reference."""
+        if DPAM_layer is not None:
+            for i in range(1, DPAM_layer):
+                self.transformer.resblocks[-i].surgery = True
 
     def _global_pool(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         return x[:, 0], x[:, 1:]

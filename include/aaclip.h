@@ -76,9 +76,14 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
  * then, if w->adapter_w: a = LeakyReLU(x Wa^T); x = mix*a*|x|/|a| + (1-mix)*x.
  * Replaces ResidualAttentionBlock.forward (reference model/transformer.py:239-258,
  * nn.MultiheadAttention at :200,237) and the adapter lines model/adapter.py:162-170
- * (visual, causal=0) / :285-295 (text, causal=1: mask of model/transformer.py:629-635).
+ * (visual, AACLIP_ATTN_FULL) / :285-295 (text, AACLIP_ATTN_CAUSAL: mask of model/transformer.py:629-635).
+ * AACLIP_ATTN_VV_BATCH: the block after VisionTransformer.DAPM_replace (reference
+ * model/transformer.py:406-425): its attention is the "surgery" module (:102-152) with
+ * q = k = v = value projection, which -- fed the LND stream -- attends over the BATCH axis per
+ * token position.  Reproduced as the reference runs it (outputs depend on the batch); needs F >= 4*D.
  * H heads of 64; D = 64*H. */
-int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int causal,
+enum { AACLIP_ATTN_FULL = 0, AACLIP_ATTN_CAUSAL = 1, AACLIP_ATTN_VV_BATCH = 2 };
+int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int attn_mode,
                  int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* Tap head: ln_post -> seg_proj (Linear no bias [+LeakyReLU]) -> F.normalize, CLS row

@@ -80,12 +80,33 @@ def self_attention(h: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
     return ctx @ out_w.t() + out_b
 
 
-def resblock(x: torch.Tensor, sd: SD, p: str, heads: int, mask: Optional[torch.Tensor]) -> torch.Tensor:
+def vv_attention_batch_axis(h: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
+                            out_w: torch.Tensor, out_b: torch.Tensor, heads: int) -> torch.Tensor:
+    """The "surgery" Attention of reference model/transformer.py:102-152 as it actually runs after
+    DAPM_replace (:406-425): q = k = v (the value projection), scores v.v^T * head_dim^-1/2, softmax,
+    out_proj.  The block feeds it the LND stream but the module unpacks `B, N, C = q_x.shape`
+    (:126), so the softmax runs over the BATCH axis, separately for every token position and head
+    (outputs depend on the batch composition).  h is batch-first [B, L, D]."""
+    B, L, D = h.shape
+    hd = D // heads
+    v = (h @ in_w.t() + in_b)[..., 2 * D:].view(B, L, heads, hd).permute(1, 2, 0, 3)   # [L, H, B, hd]
+    p = torch.softmax((v @ v.transpose(-1, -2)) * (hd ** -0.5), dim=-1)                # [L, H, B, B]
+    ctx = (p @ v).permute(2, 0, 1, 3).reshape(B, L, D)
+    return ctx @ out_w.t() + out_b
+
+
+def resblock(x: torch.Tensor, sd: SD, p: str, heads: int, mask: Optional[torch.Tensor],
+             surgery: bool = False) -> torch.Tensor:
     """ResidualAttentionBlock.forward, reference model/transformer.py:239-258
-    (ls_1/ls_2 are Identity, no ln_1_kv)."""
+    (ls_1/ls_2 are Identity, no ln_1_kv).  surgery=True: the block's attention was swapped by
+    DAPM_replace for the V-V module above (same weights)."""
     h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
-    x = x + self_attention(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
-                           sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], heads, mask)
+    if surgery:
+        x = x + vv_attention_batch_axis(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
+                                        sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], heads)
+    else:
+        x = x + self_attention(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
+                               sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], heads, mask)
     h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
     h = gelu_erf(h @ sd[p + "mlp.c_fc.weight"].t() + sd[p + "mlp.c_fc.bias"])
     return x + (h @ sd[p + "mlp.c_proj.weight"].t() + sd[p + "mlp.c_proj.bias"])
@@ -127,16 +148,20 @@ def _cast(sd: SD, dtype: torch.dtype) -> SD:
 
 
 def encode_image(img: torch.Tensor, sd: SD, heads: int, out_layers: Sequence[int],
-                 dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                 dtype: torch.dtype = torch.float32, dpam_layer: Optional[int] = None
+                 ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """CLIP.encode_image(image, out_layers), reference model/model.py:185-188 ->
     model/transformer.py:490-551 -> :295-317.  Taps are the raw residual stream
-    (incl. CLS) after 1-based layer idx in out_layers; pooled = ln_post(x[:,0]) @ proj."""
+    (incl. CLS) after 1-based layer idx in out_layers; pooled = ln_post(x[:,0]) @ proj.
+    dpam_layer: as after visual.DAPM_replace(DPAM_layer) (:406-425) -- the LAST dpam_layer-1
+    blocks use the V-V attention."""
     sd = _cast(sd, dtype)
     x = visual_stem(img.to(dtype), sd)
     layers = sum(1 for k in sd if k.startswith("visual.transformer.resblocks.") and k.endswith("ln_1.weight"))
+    n_surgery = max(dpam_layer - 1, 0) if dpam_layer is not None else 0
     taps = []
     for i in range(layers):
-        x = resblock(x, sd, f"visual.transformer.resblocks.{i}.", heads, None)
+        x = resblock(x, sd, f"visual.transformer.resblocks.{i}.", heads, None, surgery=i >= layers - n_surgery)
         if (i + 1) in out_layers:
             taps.append(x)
     pooled = layer_norm(x[:, 0], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]

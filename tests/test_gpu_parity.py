@@ -135,7 +135,7 @@ def _attn_ref(qkv, B, L, H, causal):
 
 @pytest.mark.parametrize("code", [F32, F16, BF16])
 @pytest.mark.parametrize("cfg", [(2, 1370, 2, 0), (3, 77, 4, 1), (1, 50, 1, 0), (2, 130, 2, 1), (1, 64, 1, 0),
-                                 (1, 129, 1, 1)])
+                                 (1, 129, 1, 1), (5, 1, 2, 0), (26, 3, 4, 0), (7, 2, 1, 1)])
 def test_attention(dev, code, cfg):
     lib = _lib.load()
     B, L, H, causal = cfg
@@ -505,3 +505,57 @@ def test_harness_end_to_end_vs_oracle(dev, tmp_path):
         want = FU.metrics_eval(masks, labels, omap.numpy(), oscore.numpy(), c, "Industrial")
         for k in ("pixel AUC", "pixel AP"):
             assert abs(row[k] - want[k]) <= 0.1 + 1e-9, (c, k, row, want)
+
+
+# ----------------------------------------------------------------------------
+# "CLIP surgery" tap path: VisionTransformer.DAPM_replace (reference transformer.py:102-152,406-425)
+# ----------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_surgery():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "surgery.npz"))
+
+
+@pytest.mark.parametrize("code", [F32, F16])
+@pytest.mark.parametrize("B", [3, 1])
+@pytest.mark.parametrize("dpam", [2, 3])
+def test_surgery_encode_image_vs_reference_golden(dev, golden_surgery, code, B, dpam):
+    cfg, sd, ia, ta, clip, model = build_tiny(dev, NAME[code])
+    clip.visual.DAPM_replace(DPAM_layer=dpam)
+    img = synth.synth_images(B, cfg.image_size, seed=7).to(dev)
+    with torch.no_grad():
+        pooled, taps = clip.encode_image(img, [1, 2, 3])
+    atol, rtol = TOL[code]
+    s = 4 if code != F32 else 1          # residual-stream values are O(1..5), as in the plain tap test
+    g = golden_surgery
+    assert_close(pooled, T(g[f"b{B}.dpam{dpam}.pooled"]), s * atol, rtol, "pooled")
+    for i, t in enumerate(taps):
+        assert_close(t, T(g[f"b{B}.dpam{dpam}.tap{i + 1}"]), s * atol, rtol, f"tap{i + 1}")
+
+
+def test_surgery_stage1_feature_chain(dev, golden_surgery):
+    """The consumer of the surgery taps, reference train.py:75-85, written against this build's API."""
+    cfg, sd, ia, ta, clip_surgery, _ = build_tiny(dev, "fp16")
+    _, _, _, _, clip_plain, _ = build_tiny(dev, "fp16")
+    clip_surgery.visual.DAPM_replace(DPAM_layer=3)
+    img = synth.synth_images(3, cfg.image_size, seed=7).to(dev)
+    with torch.no_grad():
+        _, patch_features = clip_surgery.encode_image(img, [1, 2, 3])
+        cls_token, _ = clip_plain.encode_image(img, [])
+        cls_token = cls_token / cls_token.norm(dim=-1, keepdim=True)
+        patch_features = [clip_surgery.visual.ln_post(t[:, 1:, :]) for t in patch_features]
+        patch_features = [t @ clip_surgery.visual.proj for t in patch_features]
+        patch_features = [t / t.norm(dim=-1, keepdim=True) for t in patch_features]
+        patch_features = [t + cls_token.unsqueeze(1) for t in patch_features]
+    for i, t in enumerate(patch_features):
+        assert_close(t, T(golden_surgery[f"train_feat{i + 1}"]), 1e-3, 1e-2, f"stage-1 feature {i + 1}")
+
+
+def test_surgery_needs_wide_workspace(dev):
+    lib = _lib.load()
+    x = torch.zeros(4 * 26, 256, device=dev)
+    w = _lib.BlockWeights()
+    rc = lib.aaclip_block(x.data_ptr(), C.byref(w), 0.0, 4, 26, 256, 4, 512, 2, F16, x.data_ptr(), 0, stream(dev))
+    assert rc != 0 and b"F >= 4*D" in lib.aaclip_last_error()
+    rc = lib.aaclip_block(x.data_ptr(), C.byref(w), 0.0, 4, 26, 256, 4, 1024, 3, F16, x.data_ptr(), 0, stream(dev))
+    assert rc != 0 and b"attn_mode" in lib.aaclip_last_error()

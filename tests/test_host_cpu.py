@@ -143,3 +143,37 @@ def test_precision_mapping(monkeypatch):
 def test_lds_swizzle_model():
     import subprocess, sys
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "lds_bank_model.py")], check=True)
+
+
+def test_checkpoint_loading_state_dict_and_torchscript(tmp_path, monkeypatch):
+    """reference model/openai.py:56-83 + model/clip.py:62-70: OpenAI files are TorchScript archives with
+    fp16 weights and three scalar extras; plain state-dict files load too.  Only tensors are read."""
+    from model.clip import create_model, load_checkpoint
+    from model.model import CLIP
+    from script_archive import save_scripted_state_dict
+    cfg = synth.tiny_cfg()
+    sd = synth.synth_clip_state_dict(cfg, seed=3)
+
+    def fresh():
+        return CLIP(cfg.embed_dim,
+                    dict(image_size=cfg.image_size, layers=cfg.vision.layers, width=cfg.vision.width,
+                         patch_size=cfg.patch_size),
+                    dict(context_length=77, vocab_size=cfg.vocab_size, width=cfg.text.width, heads=cfg.text.heads,
+                         layers=cfg.text.layers))
+    plain = str(tmp_path / "plain.pt")
+    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}}, plain)
+    m = fresh()
+    load_checkpoint(m, plain)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    extras = dict(sd, input_resolution=torch.tensor(70), context_length=torch.tensor(77), vocab_size=torch.tensor(cfg.vocab_size))
+    jit = str(tmp_path / "openai.pt")
+    save_scripted_state_dict(extras, jit, half=True)
+    m = fresh()
+    load_checkpoint(m, jit)
+    for k, v in m.state_dict().items():
+        assert v.dtype == torch.float32 and torch.equal(v, sd[k].half().float()), k
+    # create_model(pretrained="openai") picks the file up through AACLIP_CLIP_CKPT; wrong shapes fail strictly
+    monkeypatch.setenv("AACLIP_CLIP_CKPT", jit)
+    with pytest.raises(RuntimeError):
+        create_model("ViT-L-14-336", 518, pretrained="openai")

@@ -123,3 +123,32 @@ def test_full_encode_image(golden_full, full):
     close(pooled, golden_full["full.pooled"], atol=1e-4, rtol=1e-3)
     sampled(golden_full, "full.tap6", taps[0], atol=2e-4, rtol=1e-3)
     sampled(golden_full, "full.tap24", taps[1], atol=2e-4, rtol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# "CLIP surgery" tap path (reference transformer.py:102-152,406-425), golden from the reference
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_surgery():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "surgery.npz"))
+
+
+@pytest.mark.parametrize("B", [3, 1])
+@pytest.mark.parametrize("dpam", [2, 3])
+def test_surgery_encode_image_matches_reference(golden_surgery, B, dpam):
+    cfg = synth.tiny_cfg()
+    sd = synth.synth_clip_state_dict(cfg, seed=7)
+    img = synth.synth_images(B, cfg.image_size, seed=7)
+    pooled, taps = O.encode_image(img, sd, cfg.vision.heads, [1, 2, 3], dpam_layer=dpam)
+    g = golden_surgery
+    assert torch.allclose(pooled, torch.from_numpy(g[f"b{B}.dpam{dpam}.pooled"]), atol=2e-5, rtol=1e-5)
+    for i, t in enumerate(taps):
+        assert torch.allclose(t, torch.from_numpy(g[f"b{B}.dpam{dpam}.tap{i + 1}"]), atol=2e-5, rtol=1e-5), i
+
+
+def test_surgery_depends_on_batch_composition(golden_surgery):
+    """The reference quirk the restatement reproduces: attention over the batch axis."""
+    g = golden_surgery
+    assert not np.allclose(g["b3.dpam3.tap3"][:1], g["b1.dpam3.tap3"], atol=1e-3)
+    assert np.allclose(g["b3.dpam3.tap1"][:1], g["b1.dpam3.tap1"], atol=1e-5)      # block 1 is untouched
