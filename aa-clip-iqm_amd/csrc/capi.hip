@@ -96,6 +96,10 @@ int aaclip_set_gemm_variant(int v) {
 }
 
 int aaclip_debug_gemm_stamps(double* out3, int nwaves) {
+  if (nwaves < 0) {   // persistent kernel: 8 values (cycles per tile of 7 segments, tile count)
+    read_gemm_zstamps(out3);
+    return 0;
+  }
   read_gemm_stamps(out3, nwaves);
   return 0;
 }

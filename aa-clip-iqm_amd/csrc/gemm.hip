@@ -252,6 +252,11 @@ static int g_gemm_variant = 0;  // 0 auto, 1 force the 128-tile kernel, 2 force 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+  if (g_gemm_variant == 70) {   // persistent tiles (gemm256z.hip); falls through when K/64 is odd or < 4
+    if (launch_gemm256z(dtype, epi, p, s)) return;
+    launch_gemm256t(dtype, epi, p, s, 14);
+    return;
+  }
   if (g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60)) {
     // 16x16x32 MFMA shape; 6 plain, 7 overlapped LDS reads, 8/9/10 staggered with 0/1/2 DMA issues in the load
     // segment, 11..17 timing ablations / stamps of 10 (fp32-out epilogue only), 18 staggered + in-cluster reads,

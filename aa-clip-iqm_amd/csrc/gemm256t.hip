@@ -14,28 +14,14 @@
 // lane holds output column m = lane&15 and rows n = 4*(lane>>4) + j of each 16x16 tile.
 #include "common.h"
 #include "kernels.h"
+#include "mma16.h"
 
 namespace aaclip {
 
-template <typename T> struct Mma16;
-template <> struct Mma16<f16> {
-  static AACLIP_DEV f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mma16<bf16> {
-  static AACLIP_DEV f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-
-AACLIP_DEV int tile_off_id(int row, int chunk) {
-  const int rp = row >> 1;
-  return rp * 256 + (((((row & 1) << 3) | chunk) ^ (rp & 15)) << 4);
-}
-AACLIP_DEV void tile_src_id(int p, int& row, int& chunk) {
-  const int rp = p >> 4;
-  const int s = (p & 15) ^ (rp & 15);
-  row = rp * 2 + (s >> 3);
-  chunk = s & 7;
-}
-
+// Output tiles are written once and read by a later kernel, and the residual is read once: non-temporal
+// accesses keep them from displacing the operand tiles in L2 (measured: c_fc +6 %, out_proj +12 %).
+#define ST_OUT(ptr, v) __builtin_nontemporal_store(v, ptr)
+#define LD_RESID(ptr) __builtin_nontemporal_load(ptr)
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
 template <typename T, int EPI>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane) {
@@ -77,40 +63,59 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
       const int m = it * 8 + (lane >> 3), c = lane & 7;
       const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
       const int row = m_base + m;
-      if (row < p.M) *(u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8) = v;
+      if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
     }
   } else {
+    // fp32 outputs.  In the accumulator layout the 16 lanes of a quarter-wave hold 16 different rows, i.e. one
+    // global instruction would touch 64 cache lines for 1 KiB; staged through LDS (64 rows x 256 B per
+    // half, 16-B chunk ^= row & 15, conflict-free both ways) one instruction covers 4 rows x 256 B = 8 lines.
+    __syncthreads();  // every wave is done reading the operand tiles
+    char* st = smem + wave * 16384;
+    const int cc = lane & 15, rr = lane >> 4;      // read-back: chunk (4 columns) and row-in-group of this lane
+    const int n0 = n_base + cc * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS_RESID || (EPI == EPI_ACT_F32 && p.bias)) bv = *(const f32x4*)(p.bias + n0);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int row = m_base + mi * 16 + c16;
-      if (row < p.M) {
-        long orow = row;
-        const float* posr = nullptr;
+    for (int half = 0; half < 2; ++half) {
+      f32x4 extra[16];
+      long orow[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = m_base + half * 64 + it * 4 + rr;
+        orow[it] = row;
         if (EPI == EPI_PATCH) {
-          const int b = row / p.P, pi = row - b * p.P;
-          orow = (long)b * p.L + 1 + pi;
-          posr = p.pos + (long)(1 + pi) * p.N;
+          const int rc = row < p.M ? row : p.M - 1;
+          const int b = rc / p.P, pi = rc - b * p.P;
+          orow[it] = (long)b * p.L + 1 + pi;
+          extra[it] = *(const f32x4*)(p.pos + (long)(1 + pi) * p.N + n0);
+        } else if (EPI == EPI_BIAS_RESID) {
+          const long rc = row < p.M ? row : p.M - 1;
+          extra[it] = LD_RESID((const f32x4*)((const float*)p.out + rc * p.ldc + n0));
         }
-        float* op = (float*)p.out + orow * p.ldc;
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          const int n0 = n_base + ni * 16 + 4 * q4;
-          f32x4 v = acc[mi][ni];
-          if (EPI == EPI_BIAS_RESID) {
-            const f32x4 bv = *(const f32x4*)(p.bias + n0);
-            const f32x4 x = *(const f32x4*)(op + n0);
-            v = x + (v + bv);
-          } else if (EPI == EPI_ACT_F32) {
-            if (p.bias) v = v + *(const f32x4*)(p.bias + n0);
-            if (p.act == 1) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = leaky(v[j]);
-            }
-          } else if (EPI == EPI_PATCH) {
-            v = v + *(const f32x4*)(posr + n0);
-          }
-          *(f32x4*)(op + n0) = v;
+          const int m = mi * 16 + c16;
+          *(f32x4*)(st + m * 256 + (((ni * 4 + q4) ^ (m & 15)) << 4)) = acc[half * 4 + mi][ni];
         }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = it * 4 + rr;
+        f32x4 v = *(const f32x4*)(st + m * 256 + ((cc ^ (m & 15)) << 4));
+        if (EPI == EPI_BIAS_RESID) {
+          v = extra[it] + (v + bv);
+        } else if (EPI == EPI_ACT_F32) {
+          v = v + bv;
+          if (p.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = leaky(v[j]);
+          }
+        } else if (EPI == EPI_PATCH) {
+          v = v + extra[it];
+        }
+        if (m_base + half * 64 + m < p.M) ST_OUT((f32x4*)((float*)p.out + orow[it] * p.ldc + n0), v);
       }
     }
   }

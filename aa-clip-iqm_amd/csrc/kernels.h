@@ -29,6 +29,8 @@ void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s);
 bool gemm256_applicable(int dtype, const GemmParams& p);
 void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined);
 void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped);
+void read_gemm_zstamps(double* out8);   // -DZ_STAMP builds only, zeros otherwise
+bool launch_gemm256z(int dtype, int epi, const GemmParams& p, hipStream_t s);   // persistent tiles; false = not applicable
 void set_gemm_variant(int v);
 void set_tail_peel(int v);
 void read_gemm_stamps(double* out3, int nwaves);

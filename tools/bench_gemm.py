@@ -13,12 +13,13 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="1,2")
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--only", default="")
+ap.add_argument("--m", type=int, default=0, help="override the row count (default batch*1370)")
 a = ap.parse_args()
 lib = _lib.load()
 dev = torch.device("cuda:0")
 code = {"f16": _lib.F16, "bf16": _lib.BF16}[a.dtype]
 tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
-M = a.batch * 1370
+M = a.m or a.batch * 1370
 shapes = [("qkv", _lib.EPI_BIAS, 3072, 1024), ("out_proj", _lib.EPI_BIAS_RESID, 1024, 1024),
           ("c_fc", _lib.EPI_BIAS_GELU, 4096, 1024), ("c_proj", _lib.EPI_BIAS_RESID, 1024, 4096),
           ("adapter", _lib.EPI_ACT_F32, 1024, 1024), ("seg_proj", _lib.EPI_ACT_F32, 768, 1024),
