@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaaclip_hip.so")
+LIB_PATH = os.environ.get("AACLIP_LIB") or os.path.join(_HERE, "libaaclip_hip.so")   # AACLIP_LIB: experiment builds
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1

@@ -20,7 +20,7 @@ namespace aaclip {
 
 // Output tiles are written once and read by a later kernel, and the residual is read once: non-temporal
 // accesses keep them from displacing the operand tiles in L2 (measured: c_fc +6 %, out_proj +12 %).
-#define ST_OUT(ptr, v) __builtin_nontemporal_store(v, ptr)
+#define ST_OUT(ptr, v) __builtin_nontemporal_store(v, ptr)   // the nt bit is what helps; sc0/sc1 made no difference
 #define LD_RESID(ptr) __builtin_nontemporal_load(ptr)
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
 template <typename T, int EPI>
