@@ -183,9 +183,9 @@ def main():
             "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {
-                "workload": ("ViT-L/14-336 visual tower @518x518 with 4 tap layers (encode_image), batch 64 per GPU"
-                             if args.workload == "tower" else
-                             "full AA-CLIP visual side (adapters + seg/det heads + anomaly map), batch 64 per GPU"),
+                "workload": ((f"ViT-L/14-336 visual tower @518x518 with 4 tap layers (encode_image), batch {B} per GPU"
+                              if args.workload == "tower" else
+                              f"full AA-CLIP visual side (adapters + seg/det heads + anomaly map), batch {B} per GPU")),
                 "global_batch": n_gpus * B,
                 "image": "518x518",
                 "parallelism": f"dp{n_gpus}",
@@ -220,7 +220,7 @@ def traffic_from_profile(precision, batch):
     FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950), measured offline on this kernel and shape and committed under
     profiles/; null when the committed measurement does not match this run's configuration."""
-    path = os.path.join(REPO, "profiles", "r01_cfc_gemm_traffic.json")
+    path = os.path.join(REPO, "profiles", "r01b_cfc_gemm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -229,7 +229,7 @@ def traffic_from_profile(precision, batch):
     if precision != "fp16" or t.get("shape") != [batch * 1370, 4096, 1024]:
         return None
     return {"bytes": t["traffic_bytes_per_launch"], "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
-            "source": "profiles/r01_cfc_gemm_traffic.json"}
+            "source": "profiles/r01b_cfc_gemm_traffic.json"}
 
 
 def cpu_baseline(cfg, workload):
