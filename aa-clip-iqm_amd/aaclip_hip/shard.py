@@ -23,7 +23,11 @@ def gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
-    world = dist.get_world_size(group)
+    return _all_gather(local, dist.get_world_size(group), group)
+
+
+def _all_gather(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    import torch.distributed as dist
     local = local.contiguous()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local, group=group)

@@ -559,3 +559,25 @@ def test_surgery_needs_wide_workspace(dev):
     assert rc != 0 and b"F >= 4*D" in lib.aaclip_last_error()
     rc = lib.aaclip_block(x.data_ptr(), C.byref(w), 0.0, 4, 26, 256, 4, 1024, 3, F16, x.data_ptr(), 0, stream(dev))
     assert rc != 0 and b"attn_mode" in lib.aaclip_last_error()
+
+
+# ----------------------------------------------------------------------------
+# the one collective of the path on RCCL (single rank: the box has one GPU; world size 2 runs on gloo in
+# tests/test_distributed_cpu.py)
+# ----------------------------------------------------------------------------
+def test_rccl_all_gather_single_rank(dev):
+    import os
+    import torch.distributed as dist
+    from aaclip_hip import shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = synth.randn("t.rccl", (64, 768), 1.0, 5).to(dev)
+        out = shard._all_gather(x, 1)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out, x)
+        assert shard.gather_rows(x) is x            # world size 1: no collective
+    finally:
+        dist.destroy_process_group()

@@ -23,10 +23,19 @@ def run_two():
     with torch.cuda.stream(s2):
         clip.encode_image(img[32:], [6, 12, 18, 24])
     cur.wait_stream(s1); cur.wait_stream(s2)
+s3, s4 = torch.cuda.Stream(), torch.cuda.Stream()
+def run_four():
+    cur = torch.cuda.current_stream()
+    ss = (s1, s2, s3, s4)
+    for st in ss: st.wait_stream(cur)
+    for i, st in enumerate(ss):
+        with torch.cuda.stream(st):
+            clip.encode_image(img[16 * i:16 * i + 16], [6, 12, 18, 24])
+    for st in ss: cur.wait_stream(st)
 def run_seq_halves():
     clip.encode_image(img[:32], [6, 12, 18, 24]); clip.encode_image(img[32:], [6, 12, 18, 24])
 with torch.no_grad():
-    for name, fn in (("one stream, B=64", run_one), ("two halves sequential", run_seq_halves), ("two halves, two streams", run_two)):
+    for name, fn in (("one stream, B=64", run_one), ("two halves sequential", run_seq_halves), ("two halves, two streams", run_two), ("four quarters, four streams", run_four)):
         fn(); torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(3): fn()
