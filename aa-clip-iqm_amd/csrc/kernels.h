@@ -73,8 +73,9 @@ void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int 
 int resample_ksize(int in_size, int out_size);
 void resample_table(int in_size, int out_size, int32_t* bounds, int32_t* coefs);   // host buffers
 int preprocess_tile_rows(int in_size, int out_size, int ty);
+int preprocess_row_pitch(int in_w, int out_size);
 void launch_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const int32_t* hb, const int32_t* hk, int kx,
-                       const int32_t* vb, const int32_t* vk, int ky, int TY, int lds_rows, const float* lut,
+                       const int32_t* vb, const int32_t* vk, int ky, int TY, int lds_rows, int pitch, const float* lut,
                        float* out, hipStream_t s);
 
 }  // namespace aaclip

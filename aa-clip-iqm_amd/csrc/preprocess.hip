@@ -1,9 +1,11 @@
 // Image pre-processing in front of the patch embed: 8-bit bicubic resize to S x S, ToTensor,
 // Normalize -- the reference's dataset transform (reference dataset/__init__.py:150-161), whose
-// resize is Pillow's 8-bit two-pass resampler.  Integer / byte work, HBM-bound: one kernel reads
+// resize is Pillow's 8-bit two-pass resampler.  Integer / byte work: one kernel reads
 // every source pixel once (plus the tile halo), keeps the horizontally resampled rows of a tile in
 // LDS as uint8 (Pillow rounds to uint8 between its two passes, so the intermediate IS 8-bit) and
-// writes the normalised fp32 planes once.  Bit-exact with Pillow: same 22-bit fixed-point weights,
+// writes the normalised fp32 planes once.  The tile's source rectangle is first copied to LDS with
+// 16-byte loads (byte-granular gathers straight from global memory were TA-bound: 27 one-byte
+// loads per intermediate pixel).  Bit-exact with Pillow: same 22-bit fixed-point weights,
 // same int32 accumulation, same rounding and clipping; the u8 -> fp32 normalisation is a
 // 3 x 256-entry table built by the host with the very fp32 operations ToTensor/Normalize perform.
 #include "common.h"
@@ -79,20 +81,31 @@ int preprocess_tile_rows(int in_size, int out_size, int ty) {
   return (int)ceil((ty - 1) * scale) + 1 + k;
 }
 
+// LDS bytes per staged source row: the 64 output columns of a tile touch at most this many source
+// pixels; + 16 for the 16-byte alignment of the staged segment, rounded to 16.
+int preprocess_row_pitch(int in_w, int out_size) {
+  const int span = preprocess_tile_rows(in_w, out_size, PP_TX);
+  return ((span * 3 + 16 + 15) / 16) * 16;
+}
+
 // ------------------------------------------------------------------------------------- device
 AACLIP_DEV int clip8(int acc) {
   int v = acc >> PRECISION_BITS;
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// grid (ceil(S/64), ceil(S/TY), B), 256 threads.  tmp planes live in dynamic LDS: [3][rows][64] u8.
+// grid (ceil(S/64), ceil(S/TY), B), 256 threads.  Dynamic LDS: [lds_rows][pitch] source bytes (16-byte
+// aligned segments copied with 16-byte loads), then [3][lds_rows][64] uint8 planes of the horizontal pass.
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ src, int Hs, int Ws, int S,
                                                          const int32_t* __restrict__ hb, const int32_t* __restrict__ hk,
                                                          int kx, const int32_t* __restrict__ vb,
                                                          const int32_t* __restrict__ vk, int ky, int TY, int lds_rows,
-                                                         const float* __restrict__ lut, float* __restrict__ out) {
-  extern __shared__ uint8_t tmp[];
+                                                         int pitch, long total_bytes, const float* __restrict__ lut,
+                                                         float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ float s_lut[3 * 256];
+  uint8_t* stage = lds;
+  uint8_t* tmp = lds + (size_t)lds_rows * pitch;
   const int x0 = blockIdx.x * PP_TX, y0 = blockIdx.y * TY, b = blockIdx.z;
   const int ny = min(TY, S - y0), nx = min(PP_TX, S - x0);
   for (int i = threadIdx.x; i < 3 * 256; i += 256) s_lut[i] = lut[i];
@@ -100,16 +113,40 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
   const int ylast = y0 + ny - 1;
   int R = vb[2 * ylast] + vb[2 * ylast + 1] - r0;
   if (R > lds_rows) R = lds_rows;  // cannot happen when the host bound holds; never index past the tile
-  const uint8_t* img = src + (size_t)b * Hs * Ws * 3;
+  const int c0 = hb[2 * x0];
+  const int xlast = x0 + nx - 1;
+  const int c1 = hb[2 * xlast] + hb[2 * xlast + 1];
+  const long img0 = (long)b * Hs * Ws * 3;
 
-  // pass 1: horizontal, source rows r0 .. r0+R-1, columns x0 .. x0+nx-1
+  // pass 0: source rows r0 .. r0+R-1, byte range [c0*3, c1*3) of each, into LDS; a row's segment starts at
+  // its 16-byte aligned global address, so the first `shift` bytes of the LDS row are padding
+  const int chunks = pitch >> 4;
+  for (int i = threadIdx.x; i < R * chunks; i += 256) {
+    const int r = i / chunks, ch = i - r * chunks;
+    const long a0 = img0 + ((long)(r0 + r) * Ws + c0) * 3;
+    const long a = (a0 & ~15L) + ch * 16;
+    const long aend = img0 + ((long)(r0 + r) * Ws + c1) * 3;
+    if (a >= aend) continue;
+    uint8_t* d = stage + r * pitch + ch * 16;
+    if (a + 16 <= total_bytes) {
+      *(u32x4*)d = *(const u32x4*)(src + a);
+    } else {
+      for (int j = 0; j < 16; ++j) d[j] = a + j < total_bytes ? src[a + j] : 0;
+    }
+  }
+  __syncthreads();
+
+  // pass 1: horizontal, from LDS (measured: this flat one-element-per-thread form beats a lane = column /
+  // wave = row arrangement with the weights held in registers; the kernel is bound by instruction issue
+  // -- one 8-bit x 22-bit multiply-add per instruction -- not by HBM)
   for (int i = threadIdx.x; i < R * PP_TX; i += 256) {
     const int r = i / PP_TX, xl = i % PP_TX;
     if (xl >= nx) continue;
     const int x = x0 + xl;
     const int first = hb[2 * x], n = hb[2 * x + 1];
     const int32_t* k = hk + (size_t)x * kx;
-    const uint8_t* p = img + ((size_t)(r0 + r) * Ws + first) * 3;
+    const int shift = (int)((img0 + ((long)(r0 + r) * Ws + c0) * 3) & 15);
+    const uint8_t* p = stage + r * pitch + shift + (first - c0) * 3;
     int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
     for (int t = 0; t < n; ++t) {
       const int w = k[t];
@@ -143,12 +180,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 }
 
 void launch_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const int32_t* hb, const int32_t* hk, int kx,
-                       const int32_t* vb, const int32_t* vk, int ky, int TY, int lds_rows, const float* lut,
+                       const int32_t* vb, const int32_t* vk, int ky, int TY, int lds_rows, int pitch, const float* lut,
                        float* out, hipStream_t s) {
   dim3 grid((S + PP_TX - 1) / PP_TX, (S + TY - 1) / TY, B);
-  const size_t lds = (size_t)3 * lds_rows * PP_TX;
+  const size_t lds = (size_t)lds_rows * pitch + (size_t)3 * lds_rows * PP_TX;
   hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), lds, s, src, Hs, Ws, S, hb, hk, kx, vb, vk, ky, TY, lds_rows,
-                     lut, out);
+                     pitch, (long)B * Hs * Ws * 3, lut, out);
 }
 
 }  // namespace aaclip
