@@ -24,7 +24,7 @@ class BlockWeights(C.Structure):
     """struct aaclip_block_weights (include/aaclip.h)."""
     _fields_ = [(n, _vp) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b",
-        "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w")]
+        "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w", "fc_w_fold", "fc_fold_s", "fc_fold_b")]
 
 
 # name -> (restype, argtypes); every symbol include/aaclip.h declares

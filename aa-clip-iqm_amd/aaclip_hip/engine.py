@@ -128,6 +128,39 @@ class WeightCache:
 CACHE = WeightCache()
 
 
+class FoldCache:
+    """ln_2 folded into c_fc (include/aaclip.h, aaclip_block_weights): per block and dtype
+    (c_fc.weight * ln_2.weight in the compute dtype, its row sums, c_fc.bias + c_fc.weight @ ln_2.bias),
+    rebuilt when any of the four parameters changes."""
+
+    def __init__(self):
+        self._c: Dict[Tuple[int, int], tuple] = {}
+
+    def get(self, block, code: int):
+        ps = (block.mlp.c_fc.weight, block.mlp.c_fc.bias, block.ln_2.weight, block.ln_2.bias)
+        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (id(block), code)
+        hit = self._c.get(key)
+        if hit is not None and hit[0]() is block and hit[1] == sig:
+            return hit[2]
+        with torch.no_grad():
+            fw, fb, g, beta = (p.detach().float() for p in ps)
+            wf = (fw * g[None, :]).to(_TORCH_DT[code]).contiguous()
+            out = (wf, wf.float().sum(dim=1).contiguous(), (fb + fw @ beta).contiguous())
+        cache = self._c
+
+        def _drop(_ref, key=key):
+            ent = cache.get(key)
+            if ent is not None and ent[0] is _ref:
+                del cache[key]
+
+        self._c[key] = (weakref.ref(block, _drop), sig, out)
+        return out
+
+
+FOLDS = FoldCache()
+
+
 def _keep(refs: list, t: torch.Tensor) -> int:
     refs.append(t)
     return t.data_ptr()
@@ -150,6 +183,9 @@ def pack_block(block, code: int, adapter_weight: Optional[torch.Tensor]) -> Tupl
     w.proj_w = _keep(refs, CACHE.get(block.mlp.c_proj.weight, code))
     w.proj_b = _keep(refs, _f32c(block.mlp.c_proj.bias))
     w.adapter_w = _keep(refs, CACHE.get(adapter_weight, code)) if adapter_weight is not None else None
+    if code != F32:
+        wf, fs, fb = FOLDS.get(block, code)
+        w.fc_w_fold, w.fc_fold_s, w.fc_fold_b = _keep(refs, wf), _keep(refs, fs), _keep(refs, fb)
     return w, refs
 
 

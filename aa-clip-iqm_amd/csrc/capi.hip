@@ -10,6 +10,7 @@
 using namespace aaclip;
 
 static thread_local char g_err[512] = "";
+static int g_ln_fold = 1;   // aaclip_set_gemm_variant bit 17 turns the LayerNorm folding off (A/B measurements)
 
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -54,6 +55,10 @@ struct ProfScope {
 
 static inline size_t esize(int dtype) { return dtype == AACLIP_F32 ? 4 : 2; }
 static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+// aux region of the workspace: 16-bit copy of the residual rows, per-row partial sums [rows][D/64][2], (a, b) pairs
+static inline size_t aux_bytes(size_t es, long rows, int D) {
+  return up256((size_t)rows * D * es) + up256((size_t)rows * (D / 64 + 1) * 2 * 4) + up256((size_t)rows * 2 * 4);
+}
 static inline bool dtype_ok(int d) { return d == AACLIP_F32 || d == AACLIP_F16 || d == AACLIP_BF16; }
 
 extern "C" {
@@ -91,7 +96,8 @@ int aaclip_profile_end(float* ms, int* tags, int max_n) {
 int aaclip_set_gemm_variant(int v) {
   set_gemm_variant(v & 0xFF);
   set_attn_variant((v >> 8) & 0xFF);   // bits 8..15: attention kernel selection
-  set_tail_peel(((v >> 16) & 1) ? 0 : 1);  // bit 16: disable tail peeling
+  g_ln_fold = ((v >> 17) & 1) ? 0 : 1;
+  set_tail_peel((v >> 16) & 1);  // bit 16: peel the partial last round to the 128-tile kernel (measured: -1.6 %, off by default)
   return 0;
 }
 
@@ -107,17 +113,25 @@ int aaclip_debug_gemm_stamps(double* out3, int nwaves) {
 int aaclip_version(void) { return AACLIP_ABI_VERSION; }
 const char* aaclip_last_error(void) { return g_err; }
 
-size_t aaclip_workspace_bytes(int dtype, long rows, int D, int F, int E) {
+// workspace layout: [narrow: rows*max(D,640)*es] [big] [rows floats] [aux: LayerNorm folding] + slack
+struct WsLayout { size_t big_off, rowf_off, aux_off, total; };
+static WsLayout ws_layout(int dtype, long rows, int D, int F, int E) {
   const size_t es = esize(dtype);
   size_t wide = (size_t)rows * (size_t)(3 * D > F ? 3 * D : F) * es;
   size_t f32d = (size_t)rows * D * 4;
   size_t f32e = (size_t)rows * (E > 0 ? E : 1) * 4;
   size_t big = wide > f32d ? wide : f32d;
   if (f32e > big) big = f32e;
-  // [narrow: rows*max(D,640)*es] [big] [rows floats] + slack
   size_t narrow = (size_t)rows * (D > 640 ? D : 640) * es;
-  return up256(narrow) + up256(big) + up256((size_t)rows * 4) + 4096;
+  WsLayout l;
+  l.big_off = up256(narrow);
+  l.rowf_off = l.big_off + up256(big);
+  l.aux_off = l.rowf_off + up256((size_t)rows * 4);
+  l.total = l.aux_off + aux_bytes(es, rows, D) + 4096;
+  return l;
 }
+
+size_t aaclip_workspace_bytes(int dtype, long rows, int D, int F, int E) { return ws_layout(dtype, rows, D, F, E).total; }
 
 int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, long rows, int D,
                      float eps, void* stream) {
@@ -240,12 +254,33 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
   }
   memset(&p, 0, sizeof(p));
   p.A = ctx; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
+  // ln_2 folded into c_fc (include/aaclip.h, aaclip_block_weights): only where both products run on the
+  // kernels whose epilogue implements it; everywhere else the ln_2 pass runs as before
+  GemmParams fc;
+  memset(&fc, 0, sizeof(fc));
+  fc.lda = D; fc.M = M; fc.N = F; fc.K = D; fc.out = big; fc.ldc = F;
+  fc.A = narrow; fc.W = w->fc_w; fc.bias = w->fc_b;
+  const bool fold = w->fc_w_fold && w->fc_fold_s && w->fc_fold_b && g_ln_fold && gemm_routes_to_256t(dtype, p) &&
+                    gemm_routes_to_256t(dtype, fc);
+  char* aux = (char*)ws + ws_layout(dtype, rows, D, F, 0).aux_off;
+  char* x16 = aux;
+  float* partials = (float*)(aux + up256((size_t)rows * D * es));
+  float* rowab = (float*)((char*)partials + up256((size_t)rows * (D / 64 + 1) * 2 * 4));
+  if (fold) {
+    p.out16 = x16;
+    p.stats_out = partials;
+  }
   { ProfScope ps(3, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
   // x += c_proj(gelu(c_fc(ln_2 x)))
-  { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s); }
-  memset(&p, 0, sizeof(p));
-  p.A = narrow; p.lda = D; p.W = w->fc_w; p.M = M; p.N = F; p.K = D; p.bias = w->fc_b; p.out = big; p.ldc = F;
-  { ProfScope ps(4, s); launch_gemm(dtype, EPI_BIAS_GELU, p, s); }
+  if (fold) {
+    ProfScope ps(0, s);
+    launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s);
+    fc.A = x16; fc.W = w->fc_w_fold; fc.bias = w->fc_fold_b; fc.row_ab = rowab; fc.col_s = w->fc_fold_s;
+  } else {
+    ProfScope ps(0, s);
+    launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s);
+  }
+  { ProfScope ps(4, s); launch_gemm(dtype, EPI_BIAS_GELU, fc, s); }
   memset(&p, 0, sizeof(p));
   p.A = big; p.lda = F; p.W = w->proj_w; p.M = M; p.N = D; p.K = F; p.bias = w->proj_b; p.out = x; p.ldc = D;
   { ProfScope ps(5, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }

@@ -268,6 +268,15 @@ static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t
   launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : (g_gemm_variant >= 3 ? g_gemm_variant - 2 : 1));
 }
 
+// True when launch_gemm will run one of the 16x16x32 256-tile kernels (gemm256t.hip) on the whole problem:
+// those are the kernels whose epilogue implements the LayerNorm-folding options of GemmParams.
+bool gemm_routes_to_256t(int dtype, const GemmParams& p) {
+  if (dtype == AACLIP_F32 || !gemm256_applicable(dtype, p) || p.M < 4096) return false;
+  if (!(g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60))) return false;
+  if (g_tail_peel) return false;
+  return true;
+}
+
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {

@@ -22,6 +22,14 @@ namespace aaclip {
 // accesses keep them from displacing the operand tiles in L2 (measured: c_fc +6 %, out_proj +12 %).
 #define ST_OUT(ptr, v) __builtin_nontemporal_store(v, ptr)   // the nt bit is what helps; sc0/sc1 made no difference
 #define LD_RESID(ptr) __builtin_nontemporal_load(ptr)
+// sum over the 16 lanes of a DPP row (rotations by 8, 4, 2, 1), result in every lane
+AACLIP_DEV float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+  return x;
+}
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
 template <typename T, int EPI>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane) {
@@ -32,12 +40,28 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
     __syncthreads();  // every wave is done reading the operand tiles
     char* st = smem + wave * 16384;  // this wave's 128 x 64 tile of T: rows of 128 B, 16-B chunk ^= (m & 7)
+    const bool fold = p.row_ab != nullptr;   // LayerNorm folded into this product: acc -> a_m * acc + b_m * s_n
+    f32x2 ab[8];
+    if (fold) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        int row = m_base + mi * 16 + c16;
+        row = row < p.M ? row : p.M - 1;
+        ab[mi] = *(const f32x2*)(p.row_ab + 2L * row);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int nl = ni * 16 + 4 * q4;   // local column of this lane's 4 values
       const f32x4 bv = *(const f32x4*)(p.bias + n_base + nl);
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+      if (fold) sv = *(const f32x4*)(p.col_s + n_base + nl);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
+        if (fold) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[mi][ni][j] = fmaf(ab[mi][0], acc[mi][ni][j], ab[mi][1] * sv[j]);
+        }
         vec4 o;
         if (EPI == EPI_BIAS_GELU) {
           f32x2 g0 = {acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]};
@@ -115,7 +139,28 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
         } else if (EPI == EPI_PATCH) {
           v = v + extra[it];
         }
-        if (m_base + half * 64 + m < p.M) ST_OUT((f32x4*)((float*)p.out + orow[it] * p.ldc + n0), v);
+        const bool live = m_base + half * 64 + m < p.M;
+        if (live) ST_OUT((f32x4*)((float*)p.out + orow[it] * p.ldc + n0), v);
+        if (EPI == EPI_BIAS_RESID && p.out16) {
+          // LayerNorm folding: the next product reads the new residual rows in 16 bits (of THOSE rounded
+          // values the statistics are taken, so that mean and variance match what the MFMAs will see)
+          vec4 c16;
+          float ps = 0.f, pq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c16[j] = from_float<T>(v[j]);
+            const float r = to_float<T>(c16[j]);
+            ps += r;
+            pq = fmaf(r, r, pq);
+          }
+          if (live) *(vec4*)((T*)p.out16 + orow[it] * (long)p.N + n0) = c16;
+          ps = row16_sum(ps);   // the 16 lanes of a row hold this wave's 64 columns of it
+          pq = row16_sum(pq);
+          if (live && cc == 0) {
+            const f32x2 st2 = {ps, pq};
+            *(f32x2*)(p.stats_out + (orow[it] * (p.N >> 6) + (tn * 4 + wc)) * 2) = st2;
+          }
+        }
       }
     }
   }

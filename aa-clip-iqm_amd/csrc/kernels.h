@@ -22,6 +22,11 @@ struct GemmParams {
   int act;           // EPI_ACT_F32: 0 none, 1 LeakyReLU(0.01)
   const float* pos;  // EPI_PATCH: positional embedding [L, N]
   int P, L;          // EPI_PATCH: patches per image, tokens per image
+  // LayerNorm folding (16x16x32 256-tile kernels only; all null = off), see capi.hip aaclip_block:
+  void* out16;             // EPI_BIAS_RESID: also write the new residual rows in the compute dtype, [M, N]
+  float* stats_out;        // EPI_BIAS_RESID: per row and 64-column slice (sum, sum of squares) of the new rows, [M][N/64][2]
+  const float* row_ab;     // EPI_BIAS / EPI_BIAS_GELU: per row (a, b); value = a*acc + b*col_s[n] + bias[n]
+  const float* col_s;      //   [N] row sums of the (gamma-scaled) weight
 };
 
 const char* gemm_check(int dtype, int epi, const GemmParams& p);
@@ -65,6 +70,9 @@ void launch_blur_upsample(const float* pre, float* out, int B, int g, int S, int
                           hipStream_t s);
 void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int S, hipStream_t s);
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
+// LayerNorm folding: [M][slots][2] partial (sum, sumsq) -> [M][2] (rstd, -mean*rstd)
+void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s);
+bool gemm_routes_to_256t(int dtype, const GemmParams& p);   // launch_gemm will run a kernel with the folding epilogue
 // V-V "surgery" attention over the batch axis: regroup v [B*L,D] -> packed q|k|v rows l*B+b and back
 void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s);
 void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s);

@@ -385,3 +385,31 @@ void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int 
     hipLaunchKernelGGL(vv_regroup_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, B, L, D);
 }
 }  // namespace aaclip
+
+namespace aaclip {
+// LayerNorm folding: per-row partial (sum, sum of squares) of the 16-bit residual rows, one pair per 64-column
+// slice in a fixed order (deterministic), -> (a, b) = (rstd, -mean * rstd) with the biased variance and eps
+// of nn.LayerNorm (reference model/transformer.py:37-43).
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ ab,
+                                                                long rows, int slots, float inv_d, float eps) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const f32x2* p = (const f32x2*)(partials + row * slots * 2);
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < slots; ++i) {
+    const f32x2 v = p[i];
+    s += v[0];
+    q += v[1];
+  }
+  const float mean = s * inv_d;
+  float var = q * inv_d - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  const f32x2 o = {rstd, -mean * rstd};
+  *(f32x2*)(ab + 2 * row) = o;
+}
+void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, ab, rows,
+                     slots, 1.0f / D, eps);
+}
+}  // namespace aaclip

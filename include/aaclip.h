@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AACLIP_ABI_VERSION 1
+#define AACLIP_ABI_VERSION 2
 
 enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2 };
 enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1 };
@@ -60,6 +60,14 @@ typedef struct aaclip_block_weights {
   const void* proj_w;   /* mlp.c_proj.weight [D, F], dtype */
   const float* proj_b;
   const void* adapter_w; /* SimpleAdapter fc.0.weight [D, D], dtype; NULL = no adapter */
+  /* Optional (all three or none; ABI version >= 2): ln_2 folded into c_fc.  When present and the block runs
+   * on the large-batch 16-bit kernels, the ln_2 pass disappears: out_proj's epilogue also emits the new
+   * residual rows in `dtype` with per-row sums, and c_fc computes
+   *   rstd_m * (x16 . fc_w_fold^T)_mn - rstd_m * mean_m * fc_fold_s[n] + fc_fold_b[n]
+   * which equals c_fc(ln_2(x)) up to rounding.  Otherwise the fields are ignored. */
+  const void* fc_w_fold;  /* [F, D] dtype: c_fc.weight * ln_2.weight[None, :] */
+  const float* fc_fold_s; /* [F]: row sums of fc_w_fold (as stored, in fp32) */
+  const float* fc_fold_b; /* [F]: c_fc.bias + c_fc.weight @ ln_2.bias */
 } aaclip_block_weights;
 
 /* Patch embedding + class token + positional embedding + ln_pre.

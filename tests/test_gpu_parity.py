@@ -367,20 +367,55 @@ def test_full_encode_image_vs_reference_golden(dev, golden_full, full_weights):
 
 
 def test_batch_independence_and_determinism(dev, full_weights):
-    """Size-independent properties at a larger batch: image i gives the same
-    result whatever batch it is in; two runs are bit-identical."""
+    """Size-independent properties at a larger batch: two runs are bit-identical; image i gives the
+    bit-identical result in every batch served by the same kernels (B >= 3: 256-tile GEMMs with ln_2 folded
+    into c_fc; B <= 2: 128-tile GEMMs with the ln_2 pass), and the same result within the fp16 tolerance
+    across the two regimes (they differ in where ln_2's rounding happens, not in the math)."""
     model = build_full(dev, "fp16", full_weights)
     img = synth.synth_images(5, 518, seed=3).to(dev)
     with torch.no_grad():
         seg_a, det_a, _ = model(img)
         seg_b, det_b, _ = model(img)
+        seg_3, det_3, _ = model(img[1:4])
+        seg_2, det_2, _ = model(img[2:4])
         seg_1, det_1, _ = model(img[3:4])
     for a, b in zip(seg_a, seg_b):
         assert torch.equal(a, b)
     assert torch.equal(det_a, det_b)
-    for a, s in zip(seg_a, seg_1):
-        assert torch.equal(a[3:4], s)
-    assert torch.equal(det_a[3:4], det_1)
+    for a, s in zip(seg_a, seg_3):
+        assert torch.equal(a[1:4], s)
+    assert torch.equal(det_a[1:4], det_3)
+    for a, s in zip(seg_2, seg_1):
+        assert torch.equal(a[1:2], s)
+    assert torch.equal(det_2[1:2], det_1)
+    atol, rtol = TOL[F16]
+    for i, (a, s) in enumerate(zip(seg_a, seg_1)):
+        assert_close(a[3:4], s, atol, rtol, f"seg{i} across kernel regimes")
+    assert_close(det_a[3:4], det_1, atol, rtol, "det across kernel regimes")
+
+
+def test_ln_fold_matches_ln_pass(dev, full_weights):
+    """ln_2 folded into c_fc (aaclip_block_weights.fc_w_fold) against the same block with the ln_2 pass:
+    one full-size block on B = 4, both against the fp32 oracle block and against each other."""
+    lib = _lib.load()
+    cfg, sd, ia, ta = full_weights
+    model = build_full(dev, "fp16", full_weights)
+    blk = model.image_encoder.transformer.resblocks[3]
+    B, L, D = 4, 1370, 1024
+    x0 = synth.randn("t.fold.x", (B * L, D), 1.0, 9)
+    x0[:, 5] += 3.0          # a column with a large mean: the folded form must cancel it
+    outs = []
+    for flag in (0, 1 << 17):
+        lib.aaclip_set_gemm_variant(flag)
+        x = x0.clone().to(dev)
+        engine.run_block(x, blk, B, L, 16, F16)
+        outs.append(x.cpu())
+    lib.aaclip_set_gemm_variant(0)
+    ref = O.resblock(x0.view(B, L, D).double(), {k: v.double() for k, v in sd.items()},
+                     "visual.transformer.resblocks.3.", 16, None).view(B * L, D)
+    assert_close(outs[0], ref, 4e-3, 1e-2, "folded block vs oracle")
+    assert_close(outs[1], ref, 4e-3, 1e-2, "block with ln_2 pass vs oracle")
+    assert_close(outs[0], outs[1], 4e-3, 1e-2, "folded vs ln_2 pass")
 
 
 # ----------------------------------------------------------------------------

@@ -15,7 +15,7 @@ from conftest import GOLDEN, REPO
 
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
-    assert lib.aaclip_version() == 1
+    assert lib.aaclip_version() == 2
     header = open(os.path.join(REPO, "include", "aaclip.h")).read()
     declared = set(re.findall(r"\b(aaclip_[a-z_0-9]+)\s*\(", header))
     declared.discard("aaclip_block_weights")
