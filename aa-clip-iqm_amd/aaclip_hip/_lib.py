@@ -24,7 +24,8 @@ class BlockWeights(C.Structure):
     """struct aaclip_block_weights (include/aaclip.h)."""
     _fields_ = [(n, _vp) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b",
-        "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w", "fc_w_fold", "fc_fold_s", "fc_fold_b")]
+        "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w", "fc_w_fold", "fc_fold_s", "fc_fold_b",
+        "qkv_w_fold", "qkv_fold_s", "qkv_fold_b")]
 
 
 # name -> (restype, argtypes); every symbol include/aaclip.h declares
@@ -34,6 +35,7 @@ SIGNATURES = {
     "aaclip_workspace_bytes": (_sz, [_i, _l, _i, _i, _i]),
     "aaclip_patch_embed": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _sz, _vp]),
     "aaclip_block": (_i, [_vp, C.POINTER(BlockWeights), _f] + [_i] * 7 + [_vp, _sz, _vp]),
+    "aaclip_blocks": (_i, [_vp, C.POINTER(BlockWeights), _i, _f] + [_i] * 7 + [_vp, _sz, _vp]),
     "aaclip_tap_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "aaclip_det_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "aaclip_anomaly_map": (_i, [C.POINTER(_vp), _i, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),

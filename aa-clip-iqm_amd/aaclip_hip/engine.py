@@ -136,17 +136,23 @@ class FoldCache:
     def __init__(self):
         self._c: Dict[Tuple[int, int], tuple] = {}
 
+    @staticmethod
+    def _fold(weight, bias, gamma, beta, code):
+        fw, fb, g, be = (p.detach().float() for p in (weight, bias, gamma, beta))
+        wf = (fw * g[None, :]).to(_TORCH_DT[code]).contiguous()
+        return wf, wf.float().sum(dim=1).contiguous(), (fb + fw @ be).contiguous()
+
     def get(self, block, code: int):
-        ps = (block.mlp.c_fc.weight, block.mlp.c_fc.bias, block.ln_2.weight, block.ln_2.bias)
+        """-> (fc_w_fold, fc_fold_s, fc_fold_b, qkv_w_fold, qkv_fold_s, qkv_fold_b)"""
+        ps = (block.mlp.c_fc.weight, block.mlp.c_fc.bias, block.ln_2.weight, block.ln_2.bias,
+              block.attn.in_proj_weight, block.attn.in_proj_bias, block.ln_1.weight, block.ln_1.bias)
         sig = tuple((p.data_ptr(), p._version) for p in ps)
         key = (id(block), code)
         hit = self._c.get(key)
         if hit is not None and hit[0]() is block and hit[1] == sig:
             return hit[2]
         with torch.no_grad():
-            fw, fb, g, beta = (p.detach().float() for p in ps)
-            wf = (fw * g[None, :]).to(_TORCH_DT[code]).contiguous()
-            out = (wf, wf.float().sum(dim=1).contiguous(), (fb + fw @ beta).contiguous())
+            out = self._fold(*ps[:4], code) + self._fold(*ps[4:], code)
         cache = self._c
 
         def _drop(_ref, key=key):
@@ -184,8 +190,9 @@ def pack_block(block, code: int, adapter_weight: Optional[torch.Tensor]) -> Tupl
     w.proj_b = _keep(refs, _f32c(block.mlp.c_proj.bias))
     w.adapter_w = _keep(refs, CACHE.get(adapter_weight, code)) if adapter_weight is not None else None
     if code != F32:
-        wf, fs, fb = FOLDS.get(block, code)
+        wf, fs, fb, qf, qs, qb = FOLDS.get(block, code)
         w.fc_w_fold, w.fc_fold_s, w.fc_fold_b = _keep(refs, wf), _keep(refs, fs), _keep(refs, fb)
+        w.qkv_w_fold, w.qkv_fold_s, w.qkv_fold_b = _keep(refs, qf), _keep(refs, qs), _keep(refs, qb)
     return w, refs
 
 
@@ -236,6 +243,38 @@ def run_block(x: torch.Tensor, block, B: int, L: int, heads: int, code: int, cau
     ws = Workspace.for_rows(x.device, code, B * L, D, F, 0)
     _lib.check(lib.aaclip_block(x.data_ptr(), C.byref(w), float(mix), B, L, D, heads, F, int(causal), code,
                                 ws.data_ptr(), ws.numel(), _stream(x.device)), "block")
+    del refs
+
+
+def run_blocks(x: torch.Tensor, blocks: Sequence, B: int, L: int, heads: int, code: int, causal: bool = False,
+               adapter_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, mix: float = 0.0) -> None:
+    """Consecutive blocks in ONE aaclip_blocks call (in place on x [B*L, D]); nothing reads x in between, so
+    the library folds ln_1 of every block but the first into its QKV product.  Blocks flagged by
+    DAPM_replace run their V-V attention; a run must not mix the two attention modes."""
+    blocks = list(blocks)
+    if not blocks:
+        return
+    if len({bool(getattr(b, "surgery", False)) for b in blocks}) > 1:
+        raise ValueError("run_blocks: split the run where the attention mode changes")
+    mode = int(causal)
+    if getattr(blocks[0], "surgery", False):
+        if causal:
+            raise ValueError("the V-V attention block takes no mask")
+        mode = ATTN_VV_BATCH
+    require_gpu(x, "block")
+    lib = _lib.load()
+    D = x.shape[1]
+    F = blocks[0].mlp.c_fc.weight.shape[0]
+    arr = (BlockWeights * len(blocks))()
+    refs = []
+    for i, blk in enumerate(blocks):
+        aw = adapter_weights[i] if adapter_weights is not None else None
+        w, r = pack_block(blk, code, aw)
+        arr[i] = w
+        refs.append(r)
+    ws = Workspace.for_rows(x.device, code, B * L, D, F, 0)
+    _lib.check(lib.aaclip_blocks(x.data_ptr(), arr, len(blocks), float(mix), B, L, D, heads, F, mode, code,
+                                 ws.data_ptr(), ws.numel(), _stream(x.device)), "blocks")
     del refs
 
 

@@ -201,39 +201,37 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
   return finish("patch_embed");
 }
 
-int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int attn_mode,
-                 int dtype, void* ws, size_t ws_bytes, void* stream) {
-  REQUIRE(dtype_ok(dtype), "block: bad dtype");
-  REQUIRE(attn_mode >= AACLIP_ATTN_FULL && attn_mode <= AACLIP_ATTN_VV_BATCH, "block: attn_mode must be 0, 1 or 2");
-  REQUIRE(attn_mode != AACLIP_ATTN_VV_BATCH || F >= 4 * D, "block: V-V attention needs F >= 4*D workspace columns");
-  REQUIRE(x && w && ws, "block: null pointer");
+// One block.  aux_in: the aux region of the workspace holds the current rows of x in the compute dtype and their
+// (rstd, -mean*rstd) pairs, written by the previous block of the same aaclip_blocks call -- then ln_1 is folded
+// into the QKV product.  want_out: produce them for the next block (from the c_proj epilogue, or from the adapter
+// mix when the block has an adapter).  *aux_out tells the caller whether they were produced.
+static int block_impl(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F,
+                      int attn_mode, int dtype, void* ws, size_t ws_bytes, hipStream_t s, bool aux_in, bool want_out,
+                      bool* aux_out) {
+  *aux_out = false;
   REQUIRE(w->ln1_w && w->ln1_b && w->qkv_w && w->qkv_b && w->out_w && w->out_b && w->ln2_w && w->ln2_b && w->fc_w &&
               w->fc_b && w->proj_w && w->proj_b,
           "block: null weight pointer");
-  REQUIRE(B > 0 && L > 0, "block: empty batch");
-  REQUIRE(D == 64 * H, "block: D must equal 64*H (head dim 64)");
-  REQUIRE(F % 128 == 0 && F % 64 == 0, "block: F must be a multiple of 128");
-  const char* m = row_width_check(D);
-  if (m) return fail(-1, m);
-  REQUIRE(D % 128 == 0, "block: D must be a multiple of 128");
   const long rows = (long)B * L;
-  REQUIRE(rows < (1L << 31) / 4, "block: too many rows");
-  REQUIRE(ws_bytes >= aaclip_workspace_bytes(dtype, rows, D, F, 0), "block: workspace too small");
   const size_t es = esize(dtype);
   char* narrow = (char*)ws;
   char* big = narrow + up256((size_t)rows * (D > 640 ? D : 640) * es);
-  hipStream_t s = (hipStream_t)stream;
+  char* aux = (char*)ws + ws_layout(dtype, rows, D, F, 0).aux_off;
+  char* x16 = aux;
+  float* partials = (float*)(aux + up256((size_t)rows * D * es));
+  float* rowab = (float*)((char*)partials + up256((size_t)rows * (D / 64 + 1) * 2 * 4));
   const int M = (int)rows;
+  const bool folding = g_ln_fold && dtype != AACLIP_F32;
 
   GemmParams p;
-  // x += out_proj(attn(ln_1 x))
-  { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
+  // ---- x += out_proj(attn(ln_1 x))
   memset(&p, 0, sizeof(p));
   // 16-bit path: fold log2(e) into the q scale (one rounding) so the attention kernel works in log2 units
   const int log2q = dtype != AACLIP_F32;
   const float qscale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
   const char* ctx = narrow;
   if (attn_mode == AACLIP_ATTN_VV_BATCH) {
+    { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
     // only the value third of in_proj is needed; v lives behind the packed q|k|v buffer inside `big`
     char* vbuf = big + (size_t)rows * 3 * D * es;
     p.A = narrow; p.lda = D; p.W = (const char*)w->qkv_w + (size_t)2 * D * D * es; p.M = M; p.N = D; p.K = D;
@@ -249,30 +247,33 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
   } else {
     p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
     p.ldc = 3 * D; p.scale_cols = D; p.scale = qscale;
+    if (aux_in && folding && w->qkv_w_fold && w->qkv_fold_s && w->qkv_fold_b && gemm_routes_to_256t(dtype, p)) {
+      // ln_1 folded into the QKV product (include/aaclip.h, aaclip_block_weights)
+      p.A = x16; p.W = w->qkv_w_fold; p.bias = w->qkv_fold_b; p.row_ab = rowab; p.col_s = w->qkv_fold_s;
+    } else {
+      ProfScope ps(0, s);
+      launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
+    }
     { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
     { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s); }
   }
   memset(&p, 0, sizeof(p));
   p.A = ctx; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
-  // ln_2 folded into c_fc (include/aaclip.h, aaclip_block_weights): only where both products run on the
-  // kernels whose epilogue implements it; everywhere else the ln_2 pass runs as before
+  // ln_2 folded into c_fc: only where both products run on the kernels whose epilogue implements it;
+  // everywhere else the ln_2 pass runs as before
   GemmParams fc;
   memset(&fc, 0, sizeof(fc));
   fc.lda = D; fc.M = M; fc.N = F; fc.K = D; fc.out = big; fc.ldc = F;
   fc.A = narrow; fc.W = w->fc_w; fc.bias = w->fc_b;
-  const bool fold = w->fc_w_fold && w->fc_fold_s && w->fc_fold_b && g_ln_fold && gemm_routes_to_256t(dtype, p) &&
-                    gemm_routes_to_256t(dtype, fc);
-  char* aux = (char*)ws + ws_layout(dtype, rows, D, F, 0).aux_off;
-  char* x16 = aux;
-  float* partials = (float*)(aux + up256((size_t)rows * D * es));
-  float* rowab = (float*)((char*)partials + up256((size_t)rows * (D / 64 + 1) * 2 * 4));
-  if (fold) {
+  const bool fold2 = folding && w->fc_w_fold && w->fc_fold_s && w->fc_fold_b && gemm_routes_to_256t(dtype, p) &&
+                     gemm_routes_to_256t(dtype, fc);
+  if (fold2) {
     p.out16 = x16;
     p.stats_out = partials;
   }
   { ProfScope ps(3, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
-  // x += c_proj(gelu(c_fc(ln_2 x)))
-  if (fold) {
+  // ---- x += c_proj(gelu(c_fc(ln_2 x)))
+  if (fold2) {
     ProfScope ps(0, s);
     launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s);
     fc.A = x16; fc.W = w->fc_w_fold; fc.bias = w->fc_fold_b; fc.row_ab = rowab; fc.col_s = w->fc_fold_s;
@@ -283,21 +284,72 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
   { ProfScope ps(4, s); launch_gemm(dtype, EPI_BIAS_GELU, fc, s); }
   memset(&p, 0, sizeof(p));
   p.A = big; p.lda = F; p.W = w->proj_w; p.M = M; p.N = D; p.K = F; p.bias = w->proj_b; p.out = x; p.ldc = D;
+  // the c_proj epilogue can also emit the new rows in 16 bits: input of the adapter product, or (with their
+  // row sums) of the next block's folded ln_1
+  const bool emit = folding && gemm_routes_to_256t(dtype, p) && (w->adapter_w || want_out);
+  if (emit) {
+    p.out16 = x16;
+    p.stats_out = partials;
+  }
   { ProfScope ps(5, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
-  // residual adapter
+  if (emit && !w->adapter_w) {
+    ProfScope ps(0, s);
+    launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s);
+    *aux_out = true;
+  }
+  // ---- residual adapter
   if (w->adapter_w) {
     ProfScope ps(6, s);
     const void* a_in = x;
-    if (dtype != AACLIP_F32) {
+    if (emit) {
+      a_in = x16;
+    } else if (dtype != AACLIP_F32) {
       launch_cast_rows(dtype, x, narrow, rows * D, s);
       a_in = narrow;
     }
     memset(&p, 0, sizeof(p));
     p.A = a_in; p.lda = D; p.W = w->adapter_w; p.M = M; p.N = D; p.K = D; p.out = big; p.ldc = D; p.act = 1;
     launch_gemm(dtype, EPI_ACT_F32, p, s);
-    launch_adapter_mix(x, (const float*)big, rows, D, mix, s);
+    if (folding && want_out) {
+      launch_adapter_mix_fold(dtype, x, (const float*)big, rows, D, mix, x16, rowab, s);
+      *aux_out = true;
+    } else {
+      launch_adapter_mix(x, (const float*)big, rows, D, mix, s);
+    }
+  }
+  return 0;
+}
+
+int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L, int D, int H, int F,
+                  int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(dtype_ok(dtype), "block: bad dtype");
+  REQUIRE(attn_mode >= AACLIP_ATTN_FULL && attn_mode <= AACLIP_ATTN_VV_BATCH, "block: attn_mode must be 0, 1 or 2");
+  REQUIRE(attn_mode != AACLIP_ATTN_VV_BATCH || F >= 4 * D, "block: V-V attention needs F >= 4*D workspace columns");
+  REQUIRE(x && w && ws, "block: null pointer");
+  REQUIRE(n_blocks >= 1, "block: n_blocks must be positive");
+  REQUIRE(B > 0 && L > 0, "block: empty batch");
+  REQUIRE(D == 64 * H, "block: D must equal 64*H (head dim 64)");
+  REQUIRE(F % 128 == 0 && F % 64 == 0, "block: F must be a multiple of 128");
+  const char* m = row_width_check(D);
+  if (m) return fail(-1, m);
+  REQUIRE(D % 128 == 0, "block: D must be a multiple of 128");
+  const long rows = (long)B * L;
+  REQUIRE(rows < (1L << 31) / 4, "block: too many rows");
+  REQUIRE(ws_bytes >= aaclip_workspace_bytes(dtype, rows, D, F, 0), "block: workspace too small");
+  bool aux = false;
+  for (int i = 0; i < n_blocks; ++i) {
+    bool produced = false;
+    int rc = block_impl(x, w + i, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, (hipStream_t)stream, aux,
+                        i + 1 < n_blocks, &produced);
+    if (rc) return rc;
+    aux = produced;
   }
   return finish("block");
+}
+
+int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int attn_mode,
+                 int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return aaclip_blocks(x, w, 1, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, stream);
 }
 
 static int head_common(const float* x, const float* ln_w, const float* ln_b, int B, int L, int D, int E, int dtype,

@@ -51,6 +51,8 @@ const char* row_width_check(int D);
 void launch_layernorm(int out_dtype, const float* x, const float* w, const float* b, void* out, long rows, int D,
                       float eps, hipStream_t s);
 void launch_adapter_mix(float* x, const float* a, long rows, int D, float weight, hipStream_t s);
+void launch_adapter_mix_fold(int dtype, float* x, const float* a, long rows, int D, float weight, void* out16,
+                             float* rowab, hipStream_t s);   // also emits the 16-bit rows and (rstd, -mean*rstd)
 void launch_im2col(int dtype, const float* img, void* cols, int B, int C, int H, int W, int ps, int Kpad,
                    hipStream_t s);
 void launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s);

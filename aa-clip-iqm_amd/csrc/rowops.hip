@@ -88,9 +88,11 @@ void launch_layernorm(int out_dtype, const float* x, const float* w, const float
 
 // Residual adapter mix, reference model/adapter.py:165-170 (and :290-295):
 //   a <- a * |x| / |a| per token (no eps), x <- w*a + (1-w)*x, in place on x.
-template <int NCH>
+// With out16 / rowab (LayerNorm folding, capi.hip): also writes the new rows in the compute dtype and the
+// (rstd, -mean*rstd) pair of those rounded values, which the next block's QKV product folds ln_1 with.
+template <int NCH, typename T>
 __global__ __launch_bounds__(256) void adapter_mix_kernel(float* x, const float* __restrict__ a, long rows,
-                                                          float weight) {
+                                                          float weight, T* out16, float* rowab, float eps) {
   constexpr int D = NCH * 256;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -107,23 +109,55 @@ __global__ __launch_bounds__(256) void adapter_mix_kernel(float* x, const float*
       sa = fmaf(av[c][e], av[c][e], sa);
     }
   const float nx = sqrtf(wave_sum(sx)), na = sqrtf(wave_sum(sa));
+  float ps = 0.f, pq = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = weight * (av[c][e] * nx / na) + (1.0f - weight) * xv[c][e];
     *(f32x4*)(x + row * D + (c * 64 + lane) * 4) = y;
+    if (out16) {
+      store4<T>(out16 + row * D + (c * 64 + lane) * 4, y);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float r = to_float<T>(from_float<T>(y[e]));
+        ps += r;
+        pq = fmaf(r, r, pq);
+      }
+    }
+  }
+  if (out16) {
+    ps = wave_sum(ps);
+    pq = wave_sum(pq);
+    const float mean = ps * (1.0f / D);
+    float var = pq * (1.0f / D) - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) {
+      const f32x2 o = {rstd, -mean * rstd};
+      *(f32x2*)(rowab + 2 * row) = o;
+    }
   }
 }
 
-void launch_adapter_mix(float* x, const float* a, long rows, int D, float weight, hipStream_t s) {
+template <typename T>
+static void launch_adapter_mix_t(float* x, const float* a, long rows, int D, float weight, T* out16, float* rowab,
+                                 hipStream_t s) {
   dim3 g((unsigned)((rows + 3) / 4));
   switch (D / 256) {
-    case 1: hipLaunchKernelGGL(adapter_mix_kernel<1>, g, dim3(256), 0, s, x, a, rows, weight); break;
-    case 2: hipLaunchKernelGGL(adapter_mix_kernel<2>, g, dim3(256), 0, s, x, a, rows, weight); break;
-    case 3: hipLaunchKernelGGL(adapter_mix_kernel<3>, g, dim3(256), 0, s, x, a, rows, weight); break;
-    case 4: hipLaunchKernelGGL(adapter_mix_kernel<4>, g, dim3(256), 0, s, x, a, rows, weight); break;
+    case 1: hipLaunchKernelGGL((adapter_mix_kernel<1, T>), g, dim3(256), 0, s, x, a, rows, weight, out16, rowab, 1e-5f); break;
+    case 2: hipLaunchKernelGGL((adapter_mix_kernel<2, T>), g, dim3(256), 0, s, x, a, rows, weight, out16, rowab, 1e-5f); break;
+    case 3: hipLaunchKernelGGL((adapter_mix_kernel<3, T>), g, dim3(256), 0, s, x, a, rows, weight, out16, rowab, 1e-5f); break;
+    case 4: hipLaunchKernelGGL((adapter_mix_kernel<4, T>), g, dim3(256), 0, s, x, a, rows, weight, out16, rowab, 1e-5f); break;
   }
+}
+void launch_adapter_mix(float* x, const float* a, long rows, int D, float weight, hipStream_t s) {
+  launch_adapter_mix_t<f16>(x, a, rows, D, weight, nullptr, nullptr, s);
+}
+void launch_adapter_mix_fold(int dtype, float* x, const float* a, long rows, int D, float weight, void* out16,
+                             float* rowab, hipStream_t s) {
+  if (dtype == AACLIP_BF16) launch_adapter_mix_t<bf16>(x, a, rows, D, weight, (bf16*)out16, rowab, s);
+  else launch_adapter_mix_t<f16>(x, a, rows, D, weight, (f16*)out16, rowab, s);
 }
 
 // Unfold non-overlapping ps x ps patches of an NCHW fp32 image into GEMM rows:

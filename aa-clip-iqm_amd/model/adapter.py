@@ -76,9 +76,14 @@ class AdaptedCLIP(nn.Module):
         seg_tokens: List[torch.Tensor] = []
         det_token = None
         n_levels = len(self.levels)
-        for i, blk in enumerate(v.transformer.resblocks):
-            aw = adapters[i].weight if i < self.image_adapt_until else None
-            engine.run_block(xs, blk, B, L, heads, code, causal=False, adapter_weight=aw, mix=self.i_w)
+        blocks = list(v.transformer.resblocks)
+        run, run_aw = [], []   # consecutive blocks up to the next tap: one aaclip_blocks call
+        for i, blk in enumerate(blocks):
+            run.append(blk)
+            run_aw.append(adapters[i].weight if i < self.image_adapt_until else None)
+            if (i + 1) in self.levels or i + 1 == len(blocks):
+                engine.run_blocks(xs, run, B, L, heads, code, causal=False, adapter_weights=run_aw, mix=self.i_w)
+                run, run_aw = [], []
             if (i + 1) in self.levels:
                 k = len(seg_tokens)
                 last = k == n_levels - 1
@@ -99,7 +104,7 @@ class AdaptedCLIP(nn.Module):
         x, tk = engine.text_embed(text, c.token_embedding.weight, c.positional_embedding)
         n, T = tk.shape
         heads = c.transformer.heads
-        for i, blk in enumerate(c.transformer.resblocks):
-            aw = self.text_adapter[i].weight if i < self.text_adapt_until else None
-            engine.run_block(x, blk, n, T, heads, code, causal=True, adapter_weight=aw, mix=self.t_w)
+        blocks = list(c.transformer.resblocks)
+        aws = [self.text_adapter[i].weight if i < self.text_adapt_until else None for i in range(len(blocks))]
+        engine.run_blocks(x, blocks, n, T, heads, code, causal=True, adapter_weights=aws, mix=self.t_w)
         return engine.row_head(x, tk, c.ln_final, self.text_adapter[-1].weight, "plain", True, n, T, 0, code)

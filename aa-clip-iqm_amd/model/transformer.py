@@ -127,8 +127,16 @@ class Transformer(nn.Module):
         """Batch-first in-place tower; returns clones of the stream after the
         1-based layers in out_layers (reference transformer.py:295-317)."""
         taps = []
+        run: list = []   # consecutive blocks nobody looks between: one aaclip_blocks call
+        n = len(self.resblocks)
         for i, blk in enumerate(self.resblocks):
-            engine.run_block(x, blk, B, L, self.heads, code, causal=causal)
+            run.append(blk)
+            nxt = self.resblocks[i + 1] if i + 1 < n else None
+            boundary = (i + 1) in out_layers or nxt is None or \
+                bool(getattr(nxt, "surgery", False)) != bool(getattr(blk, "surgery", False))
+            if boundary:
+                engine.run_blocks(x, run, B, L, self.heads, code, causal=causal)
+                run = []
             if (i + 1) in out_layers:
                 taps.append(x.clone())
         return taps

@@ -68,6 +68,11 @@ typedef struct aaclip_block_weights {
   const void* fc_w_fold;  /* [F, D] dtype: c_fc.weight * ln_2.weight[None, :] */
   const float* fc_fold_s; /* [F]: row sums of fc_w_fold (as stored, in fp32) */
   const float* fc_fold_b; /* [F]: c_fc.bias + c_fc.weight @ ln_2.bias */
+  /* The same for ln_1 and the QKV product; used by aaclip_blocks for every block after the first of a call
+   * (the previous block's last epilogue, or its adapter mix, emits the 16-bit rows and their statistics). */
+  const void* qkv_w_fold;  /* [3D, D] dtype: in_proj_weight * ln_1.weight[None, :] */
+  const float* qkv_fold_s; /* [3D] */
+  const float* qkv_fold_b; /* [3D]: in_proj_bias + in_proj_weight @ ln_1.bias */
 } aaclip_block_weights;
 
 /* Patch embedding + class token + positional embedding + ln_pre.
@@ -93,6 +98,13 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
 enum { AACLIP_ATTN_FULL = 0, AACLIP_ATTN_CAUSAL = 1, AACLIP_ATTN_VV_BATCH = 2 };
 int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int attn_mode,
                  int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* n_blocks consecutive blocks (w[0..n_blocks-1], same mix / shape / attn_mode) in one call, in place on x.
+ * Identical to n_blocks aaclip_block calls, except that nothing else can touch x in between, which lets the
+ * library fold ln_1 of blocks 1..n-1 into their QKV products (see aaclip_block_weights).  Callers split the
+ * tower at the layers whose output they read (reference model/adapter.py:171-172 taps). */
+int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L, int D, int H, int F,
+                  int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* Tap head: ln_post -> seg_proj (Linear no bias [+LeakyReLU]) -> F.normalize, CLS row
  * dropped.  Replaces reference model/adapter.py:171-182.  x [B*L, D] fp32 (tap of the

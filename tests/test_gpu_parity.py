@@ -616,3 +616,30 @@ def test_rccl_all_gather_single_rank(dev):
         assert shard.gather_rows(x) is x            # world size 1: no collective
     finally:
         dist.destroy_process_group()
+
+
+def test_blocks_run_folds_ln1_across_blocks(dev, full_weights):
+    """aaclip_blocks (ln_1 of blocks 1.. folded into their QKV products, adapters feeding the fold) against the
+    same blocks called one by one (ln_1 passes), B = 4 so that the large-batch kernels run; both against the
+    fp32 oracle.  Blocks 4..6 of the adapted tower: two with an adapter, one without."""
+    cfg, sd, ia, ta = full_weights
+    model = build_full(dev, "fp16", full_weights)
+    blocks = list(model.image_encoder.transformer.resblocks[4:7])
+    aws = [model.image_adapter["layer_adapters"][4].weight, model.image_adapter["layer_adapters"][5].weight, None]
+    B, L, D = 4, 1370, 1024
+    x0 = synth.randn("t.run.x", (B * L, D), 1.0, 11)
+    xa = x0.clone().to(dev)
+    engine.run_blocks(xa, blocks, B, L, 16, F16, adapter_weights=aws, mix=0.1)
+    xb = x0.clone().to(dev)
+    for blk, aw in zip(blocks, aws):
+        engine.run_block(xb, blk, B, L, 16, F16, adapter_weight=aw, mix=0.1)
+    ref = x0.view(B, L, D).double()
+    sdd = {k: v.double() for k, v in sd.items()}
+    for i in (4, 5, 6):
+        ref = O.resblock(ref, sdd, f"visual.transformer.resblocks.{i}.", 16, None)
+        if i < 6:
+            ref = O.adapter_mix(ref, ia[f"layer_adapters.{i}.fc.0.weight"].double(), 0.1)
+    ref = ref.view(B * L, D)
+    assert_close(xa, ref, 6e-3, 1e-2, "one aaclip_blocks call vs oracle")
+    assert_close(xb, ref, 6e-3, 1e-2, "block by block vs oracle")
+    assert_close(xa, xb, 6e-3, 1e-2, "one call vs block by block")
