@@ -22,6 +22,11 @@ namespace aaclip {
 // accesses keep them from displacing the operand tiles in L2 (measured: c_fc +6 %, out_proj +12 %).
 #define ST_OUT(ptr, v) __builtin_nontemporal_store(v, ptr)   // the nt bit is what helps; sc0/sc1 made no difference
 #define LD_RESID(ptr) __builtin_nontemporal_load(ptr)
+template <typename P> AACLIP_DEV P* uniform_ptr(P* ptr) {
+  const unsigned long long a = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (P*)(((unsigned long long)hi << 32) | lo);
+}
 // sum over the 16 lanes of a DPP row (rotations by 8, 4, 2, 1), result in every lane
 AACLIP_DEV float row16_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
@@ -34,6 +39,10 @@ AACLIP_DEV float row16_sum(float x) {
 template <typename T, int EPI>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane) {
   typedef typename Elem<T>::vec4 vec4;
+  // Everything the epilogue addresses with is derived from `lane` below this point: the empty asm keeps hipcc from
+  // computing it before the K loop and carrying it through (measured: the folding code alone cost the residual
+  // GEMMs 15 % that way, with the K loop unchanged in source).
+  asm volatile("" : "+v"(lane));
   const int c16 = lane & 15, q4 = lane >> 4;
   const int wr = wave >> 2, wc = wave & 3;
   const int m_base = tm * 256 + wr * 128, n_base = tn * 256 + wc * 64;
@@ -943,8 +952,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
       srcW[sub][j] = (row * p.K + chunk * 8) * 2;
       dstW[sub][j] = 32768 + gw * 1024;
     }
-  const T* baseA = (const T*)p.A + (long)tm * 256 * p.lda;
-  const T* baseW = (const T*)p.W + (long)tn * 256 * p.K;
+  // the descriptors must be PROVABLY wave-uniform, or hipcc wraps every buffer_load ... lds of the K loop in a
+  // waterfall loop (v_readfirstlane x4, compare, s_and_saveexec): it lost the proof when the folding epilogue was
+  // added and the residual GEMMs ran 15 % slower with an unchanged K loop in source
+  const T* baseA = uniform_ptr((const T*)p.A + (long)tm * 256 * p.lda);
+  const T* baseW = uniform_ptr((const T*)p.W + (long)tn * 256 * p.K);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7FFFFFF0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
   int offM[2][2], offN[2][2];   // [ks][tile parity]
