@@ -37,7 +37,8 @@ AACLIP_DEV float row16_sum(float x) {
 }
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
 template <typename T, int EPI>
-AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane) {
+AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane,
+                             const f32x2* ab_pre = nullptr) {
   typedef typename Elem<T>::vec4 vec4;
   // Everything the epilogue addresses with is derived from `lane` below this point: the empty asm keeps hipcc from
   // computing it before the K loop and carrying it through (measured: the folding code alone cost the residual
@@ -54,9 +55,13 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
     if (fold) {
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
-        int row = m_base + mi * 16 + c16;
-        row = row < p.M ? row : p.M - 1;
-        ab[mi] = *(const f32x2*)(p.row_ab + 2L * row);
+        if (ab_pre) {
+          ab[mi] = ab_pre[mi];   // fetched before the K loop by the caller (their latency is exposed here otherwise)
+        } else {
+          int row = m_base + mi * 16 + c16;
+          row = row < p.M ? row : p.M - 1;
+          ab[mi] = *(const f32x2*)(p.row_ab + 2L * row);
+        }
       }
     }
 #pragma unroll
@@ -975,6 +980,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  // LayerNorm folding: this lane's (rstd, -mean*rstd) pairs, requested now so that they are there at the epilogue
+  f32x2 ab_pre[8];
+  const bool fold_pre = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.row_ab != nullptr;
+  if (fold_pre) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      int row = tm * 256 + wr * 128 + mi * 16 + c16;
+      row = row < p.M ? row : p.M - 1;
+      ab_pre[mi] = *(const f32x2*)(p.row_ab + 2L * row);
+    }
+  }
 
   const int nk = p.K >> 6;
 #define DMA(rs, src, dst, st, kt) \
@@ -1065,7 +1081,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef MM
 #undef QUADX
 #undef KTILE
-  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
 }
 
 template <typename T>
