@@ -50,6 +50,7 @@ SIGNATURES = {
     "aaclip_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "aaclip_set_gemm_variant": (_i, [_i]),
+    "aaclip_debug_gemm_stamps": (_i, [C.POINTER(C.c_double), _i]),
     "aaclip_profile_begin": (_i, [C.c_uint, _i]),
     "aaclip_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
 }

@@ -173,9 +173,19 @@ int aaclip_row_head(const float* x, const int32_t* tokens, const float* ln_w, co
 int aaclip_profile_begin(unsigned tag_mask, int capacity);
 int aaclip_profile_end(float* ms, int* tags, int max_n);
 
-/* Kernel selection for A/B measurements: 0 = automatic (default), 1 = always the 128x128-tile
- * GEMM, 2 = the 256x256-tile GEMM wherever its shape constraints hold. */
+/* Kernel selection for A/B measurements (tools/bench_gemm.py, tools/bench_attn.py); 0 = automatic (default).
+ * bits 0..7   GEMM: 1 = always the 128x128-tile kernel; 2..5 = 256-tile kernels on 32x32x16 MFMAs; 6..60 = the
+ *             16x16x32 family (20 = the default kernel, others: lock-step / in-cluster-read variants, timing
+ *             ablations and the stamp build); 70 = persistent tiles (gemm256z.hip)
+ * bits 8..15  attention: 1 = always the 128-query kernel, 2 = software-pipelined kernel
+ * bit 16      peel the partial last round of 256-tile GEMMs to the 128-tile kernel (off by default: -1.6 %)
+ * bit 17      turn the LayerNorm folding of aaclip_block(s) off */
 int aaclip_set_gemm_variant(int v);
+
+/* Diagnostics of stamp builds (tools/gemm_stamps.py, tools/gemm_zstamps.py): nwaves >= 0 -> 6 averaged s_memtime
+ * segment sums of GEMM variant 17; nwaves < 0 -> 8 values of the persistent kernel built with -DZ_STAMP (zeros in
+ * a normal build).  `out` is HOST memory. */
+int aaclip_debug_gemm_stamps(double* out, int nwaves);
 
 /* Building blocks, exported for unit parity tests and for callers that fuse differently. */
 int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, long rows, int D,
