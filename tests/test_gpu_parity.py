@@ -618,21 +618,22 @@ def test_rccl_all_gather_single_rank(dev):
         dist.destroy_process_group()
 
 
-def test_blocks_run_folds_ln1_across_blocks(dev, full_weights):
+@pytest.mark.parametrize("code", [F16, BF16])
+def test_blocks_run_folds_ln1_across_blocks(dev, full_weights, code):
     """aaclip_blocks (ln_1 of blocks 1.. folded into their QKV products, adapters feeding the fold) against the
     same blocks called one by one (ln_1 passes), B = 4 so that the large-batch kernels run; both against the
     fp32 oracle.  Blocks 4..6 of the adapted tower: two with an adapter, one without."""
     cfg, sd, ia, ta = full_weights
-    model = build_full(dev, "fp16", full_weights)
+    model = build_full(dev, NAME[code], full_weights)
     blocks = list(model.image_encoder.transformer.resblocks[4:7])
     aws = [model.image_adapter["layer_adapters"][4].weight, model.image_adapter["layer_adapters"][5].weight, None]
     B, L, D = 4, 1370, 1024
     x0 = synth.randn("t.run.x", (B * L, D), 1.0, 11)
     xa = x0.clone().to(dev)
-    engine.run_blocks(xa, blocks, B, L, 16, F16, adapter_weights=aws, mix=0.1)
+    engine.run_blocks(xa, blocks, B, L, 16, code, adapter_weights=aws, mix=0.1)
     xb = x0.clone().to(dev)
     for blk, aw in zip(blocks, aws):
-        engine.run_block(xb, blk, B, L, 16, F16, adapter_weight=aw, mix=0.1)
+        engine.run_block(xb, blk, B, L, 16, code, adapter_weight=aw, mix=0.1)
     ref = x0.view(B, L, D).double()
     sdd = {k: v.double() for k, v in sd.items()}
     for i in (4, 5, 6):
@@ -640,6 +641,29 @@ def test_blocks_run_folds_ln1_across_blocks(dev, full_weights):
         if i < 6:
             ref = O.adapter_mix(ref, ia[f"layer_adapters.{i}.fc.0.weight"].double(), 0.1)
     ref = ref.view(B * L, D)
-    assert_close(xa, ref, 6e-3, 1e-2, "one aaclip_blocks call vs oracle")
-    assert_close(xb, ref, 6e-3, 1e-2, "block by block vs oracle")
-    assert_close(xa, xb, 6e-3, 1e-2, "one call vs block by block")
+    atol, rtol = (6e-3, 1e-2) if code == F16 else (5e-2, 5e-2)
+    assert_close(xa, ref, atol, rtol, "one aaclip_blocks call vs oracle")
+    assert_close(xb, ref, atol, rtol, "block by block vs oracle")
+    assert_close(xa, xb, atol, rtol, "one call vs block by block")
+
+
+def test_text_tower_large_batch_folds_like_small_batches(dev, full_weights):
+    """encode_text on 64 sentences (M = 4928 rows: the 256-tile kernels with LayerNorm folding, width 768, causal)
+    against the same sentences encoded 8 at a time (128-tile kernels, LayerNorm passes) and against the oracle."""
+    cfg, sd, ia, ta = full_weights
+    model = build_full(dev, "fp16", full_weights)
+    import forward_utils as FU
+    from model.tokenizer import tokenize
+    sentences = []
+    for c in ("bottle", "cable", "capsule", "carpet"):
+        for group in FU.class_sentences("MVTec", c):
+            sentences.extend(group)
+    sentences = sentences[:64]
+    tok = tokenize(sentences).to(dev)
+    with torch.no_grad():
+        big = model.encode_text(tok)
+        small = torch.cat([model.encode_text(tok[i:i + 8]) for i in range(0, 64, 8)])
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)
+    assert_close(unit(big), unit(small), 1e-3, 1e-2, "64 sentences at once vs 8 at a time")
+    ref = O.adapted_encode_text(tok[:4].cpu(), sd, ta, cfg.text.heads)
+    assert_close(unit(big[:4]), unit(ref), 1e-3, 1e-2, "folded text tower vs oracle")
