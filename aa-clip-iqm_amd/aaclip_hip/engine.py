@@ -247,10 +247,12 @@ def run_block(x: torch.Tensor, block, B: int, L: int, heads: int, code: int, cau
 
 
 def run_blocks(x: torch.Tensor, blocks: Sequence, B: int, L: int, heads: int, code: int, causal: bool = False,
-               adapter_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, mix: float = 0.0) -> None:
+               adapter_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, mix: float = 0.0,
+               x_out: Optional[torch.Tensor] = None) -> None:
     """Consecutive blocks in ONE aaclip_blocks call (in place on x [B*L, D]); nothing reads x in between, so
     the library folds ln_1 of every block but the first into its QKV product.  Blocks flagged by
-    DAPM_replace run their V-V attention; a run must not mix the two attention modes."""
+    DAPM_replace run their V-V attention; a run must not mix the two attention modes.
+    x_out: leave x untouched and continue the stream in x_out (aaclip_blocks_to) -- x stays valid as a tap."""
     blocks = list(blocks)
     if not blocks:
         return
@@ -273,8 +275,13 @@ def run_blocks(x: torch.Tensor, blocks: Sequence, B: int, L: int, heads: int, co
         arr[i] = w
         refs.append(r)
     ws = Workspace.for_rows(x.device, code, B * L, D, F, 0)
-    _lib.check(lib.aaclip_blocks(x.data_ptr(), arr, len(blocks), float(mix), B, L, D, heads, F, mode, code,
-                                 ws.data_ptr(), ws.numel(), _stream(x.device)), "blocks")
+    if x_out is not None:
+        require_gpu(x_out, "block")
+        if x_out.shape != x.shape or x_out.dtype != torch.float32 or not x_out.is_contiguous():
+            raise ValueError("x_out must be a contiguous fp32 tensor of x's shape")
+    dst = x if x_out is None else x_out
+    _lib.check(lib.aaclip_blocks_to(x.data_ptr(), dst.data_ptr(), arr, len(blocks), float(mix), B, L, D, heads, F, mode,
+                                    code, ws.data_ptr(), ws.numel(), _stream(x.device)), "blocks")
     del refs
 
 

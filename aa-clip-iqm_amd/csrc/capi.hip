@@ -205,9 +205,11 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
 // (rstd, -mean*rstd) pairs, written by the previous block of the same aaclip_blocks call -- then ln_1 is folded
 // into the QKV product.  want_out: produce them for the next block (from the c_proj epilogue, or from the adapter
 // mix when the block has an adapter).  *aux_out tells the caller whether they were produced.
-static int block_impl(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F,
-                      int attn_mode, int dtype, void* ws, size_t ws_bytes, hipStream_t s, bool aux_in, bool want_out,
-                      bool* aux_out) {
+// x_in != x: the block READS the stream from x_in (left untouched) and continues it in x -- the first residual
+// update (out_proj) takes its residual from x_in and writes x.
+static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H,
+                      int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, hipStream_t s, bool aux_in,
+                      bool want_out, bool* aux_out) {
   *aux_out = false;
   REQUIRE(w->ln1_w && w->ln1_b && w->qkv_w && w->qkv_b && w->out_w && w->out_b && w->ln2_w && w->ln2_b && w->fc_w &&
               w->fc_b && w->proj_w && w->proj_b,
@@ -231,7 +233,7 @@ static int block_impl(float* x, const aaclip_block_weights* w, float mix, int B,
   const float qscale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
   const char* ctx = narrow;
   if (attn_mode == AACLIP_ATTN_VV_BATCH) {
-    { ProfScope ps(0, s); launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
+    { ProfScope ps(0, s); launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
     // only the value third of in_proj is needed; v lives behind the packed q|k|v buffer inside `big`
     char* vbuf = big + (size_t)rows * 3 * D * es;
     p.A = narrow; p.lda = D; p.W = (const char*)w->qkv_w + (size_t)2 * D * D * es; p.M = M; p.N = D; p.K = D;
@@ -252,13 +254,14 @@ static int block_impl(float* x, const aaclip_block_weights* w, float mix, int B,
       p.A = x16; p.W = w->qkv_w_fold; p.bias = w->qkv_fold_b; p.row_ab = rowab; p.col_s = w->qkv_fold_s;
     } else {
       ProfScope ps(0, s);
-      launch_layernorm(dtype, x, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
+      launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
     }
     { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
     { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s); }
   }
   memset(&p, 0, sizeof(p));
   p.A = ctx; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
+  if (x_in != x) p.resid = x_in;
   // ln_2 folded into c_fc: only where both products run on the kernels whose epilogue implements it;
   // everywhere else the ln_2 pass runs as before
   GemmParams fc;
@@ -322,6 +325,12 @@ static int block_impl(float* x, const aaclip_block_weights* w, float mix, int B,
 
 int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L, int D, int H, int F,
                   int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return aaclip_blocks_to(x, x, w, n_blocks, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, stream);
+}
+
+int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L,
+                     int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(x_in, "block: null pointer");
   REQUIRE(dtype_ok(dtype), "block: bad dtype");
   REQUIRE(attn_mode >= AACLIP_ATTN_FULL && attn_mode <= AACLIP_ATTN_VV_BATCH, "block: attn_mode must be 0, 1 or 2");
   REQUIRE(attn_mode != AACLIP_ATTN_VV_BATCH || F >= 4 * D, "block: V-V attention needs F >= 4*D workspace columns");
@@ -339,8 +348,8 @@ int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float m
   bool aux = false;
   for (int i = 0; i < n_blocks; ++i) {
     bool produced = false;
-    int rc = block_impl(x, w + i, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, (hipStream_t)stream, aux,
-                        i + 1 < n_blocks, &produced);
+    int rc = block_impl(i == 0 ? x_in : x, x, w + i, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes,
+                        (hipStream_t)stream, aux, i + 1 < n_blocks, &produced);
     if (rc) return rc;
     aux = produced;
   }

@@ -33,7 +33,8 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
   } else if (EPI == EPI_BIAS_RESID) {
     float* x = (float*)p.out + (long)row * p.ldc + col;
-    *x = *x + (v + p.bias[col]);
+    const float r = p.resid ? p.resid[(long)row * p.ldc + col] : *x;
+    *x = r + (v + p.bias[col]);
   } else if (EPI == EPI_ACT_F32) {
     if (p.bias) v += p.bias[col];
     if (p.act == 1) v = leaky(v);

@@ -85,7 +85,7 @@ AACLIP_DEV void epilogue256(const GemmParams& p, f32x16 (&acc)[4][2], char* smem
             for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * g + j];
             if (EPI == EPI_BIAS_RESID) {
               const f32x4 bv = *(const f32x4*)(p.bias + n0);
-              const f32x4 x = *(const f32x4*)(op + n0);
+              const f32x4 x = *(const f32x4*)((p.resid ? p.resid + orow * p.ldc : (const float*)op) + n0);
               v = x + (v + bv);
             } else if (EPI == EPI_ACT_F32) {
               if (p.bias) v = v + *(const f32x4*)(p.bias + n0);

@@ -112,7 +112,7 @@ AACLIP_DEV void epilogue256z(const GemmParams& p, f32x4 (&acc)[8][4], char* stg,
           extra[it] = *(const f32x4*)(p.pos + (long)(1 + pi) * p.N + n0);
         } else if (EPI == EPI_BIAS_RESID) {
           const long rc = row < p.M ? row : p.M - 1;
-          extra[it] = *(const f32x4*)((const float*)p.out + rc * p.ldc + n0);
+          extra[it] = *(const f32x4*)((p.resid ? p.resid : (const float*)p.out) + rc * p.ldc + n0);
         }
       }
 #pragma unroll

@@ -22,6 +22,7 @@ struct GemmParams {
   int act;           // EPI_ACT_F32: 0 none, 1 LeakyReLU(0.01)
   const float* pos;  // EPI_PATCH: positional embedding [L, N]
   int P, L;          // EPI_PATCH: patches per image, tokens per image
+  const float* resid;      // EPI_BIAS_RESID: where the residual is READ ([M, ldc] fp32); null = in place, from `out`
   // LayerNorm folding (16x16x32 256-tile kernels only; all null = off), see capi.hip aaclip_block:
   void* out16;             // EPI_BIAS_RESID: also write the new residual rows in the compute dtype, [M, N]
   float* stats_out;        // EPI_BIAS_RESID: per row and 64-column slice (sum, sum of squares) of the new rows, [M][N/64][2]

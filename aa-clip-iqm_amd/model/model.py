@@ -84,7 +84,7 @@ class CLIP(nn.Module):
         code = engine.dtype_code(getattr(self, "precision", "fp32"))
         x, tk = engine.text_embed(text, self.token_embedding.weight, self.positional_embedding)
         n, T = tk.shape
-        self.transformer.run(x, n, T, code, True)
+        x, _ = self.transformer.run(x, n, T, code, True)
         out = engine.row_head(x, tk, self.ln_final, self.text_projection, "transpose", False, n, T, 0, code)
         if normalize:
             raise NotImplementedError("normalize=True is not used on the AA-CLIP path")

@@ -124,28 +124,38 @@ class Transformer(nn.Module):
         return self.resblocks[0].mlp.c_fc.weight.dtype
 
     def run(self, x: torch.Tensor, B: int, L: int, code: int, causal: bool, out_layers: Sequence[int] = ()):
-        """Batch-first in-place tower; returns clones of the stream after the
-        1-based layers in out_layers (reference transformer.py:295-317)."""
+        """Batch-first tower -> (final stream, [stream after the 1-based layers in out_layers]) (reference
+        transformer.py:295-317).  Without taps the tower runs in place on x; a tapped buffer is never written
+        again (the next run continues in a fresh one), so taps cost no copy and the final stream may live in a
+        different tensor than x."""
         taps = []
         run: list = []   # consecutive blocks nobody looks between: one aaclip_blocks call
         n = len(self.resblocks)
+        cur = x          # buffer holding the stream; after a tap the next run continues in a fresh one
+        tapped = False
         for i, blk in enumerate(self.resblocks):
             run.append(blk)
             nxt = self.resblocks[i + 1] if i + 1 < n else None
             boundary = (i + 1) in out_layers or nxt is None or \
                 bool(getattr(nxt, "surgery", False)) != bool(getattr(blk, "surgery", False))
             if boundary:
-                engine.run_blocks(x, run, B, L, self.heads, code, causal=causal)
+                if tapped:   # `cur` was handed out as a tap: read it, write the continuation elsewhere (no copy)
+                    fresh = torch.empty_like(cur)
+                    engine.run_blocks(cur, run, B, L, self.heads, code, causal=causal, x_out=fresh)
+                    cur, tapped = fresh, False
+                else:
+                    engine.run_blocks(cur, run, B, L, self.heads, code, causal=causal)
                 run = []
             if (i + 1) in out_layers:
-                taps.append(x.clone())
-        return taps
+                taps.append(cur)
+                tapped = True
+        return cur, taps
 
     def forward(self, x: torch.Tensor, out_layers: list = [3, 6, 9], attn_mask: Optional[torch.Tensor] = None):
         L, B, D = x.shape
         xb = x.detach().permute(1, 0, 2).float().contiguous().view(B * L, D)
         code = engine.dtype_code(getattr(self, "precision", "fp32"))
-        taps = self.run(xb, B, L, code, attn_mask is not None, out_layers)
+        xb, taps = self.run(xb, B, L, code, attn_mask is not None, out_layers)
         lnd = lambda t: t.view(B, L, D).permute(1, 0, 2)
         return lnd(xb), [lnd(t) for t in taps]
 
@@ -206,7 +216,7 @@ class VisionTransformer(nn.Module):
         """reference transformer.py:490-551 -> (pooled [B,E], [tokens [B,L,D] at out_layers])."""
         code = engine.dtype_code(getattr(self, "precision", "fp32"))
         xs, B, L = engine.patch_embed(x, self, code)
-        taps = self.transformer.run(xs, B, L, code, False, out_layers)
+        xs, taps = self.transformer.run(xs, B, L, code, False, out_layers)
         pooled = engine.row_head(xs, None, self.ln_post, self.proj, "transpose", False, B, L, 1, code)
         D = self.embed_dim
         return pooled, [t.view(B, L, D) for t in taps]

@@ -106,6 +106,13 @@ int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int 
 int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L, int D, int H, int F,
                   int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* As aaclip_blocks, but the stream is READ from x_in, which stays untouched, and continued in x (the first residual
+ * update reads x_in and writes x; x_in == x is aaclip_blocks).  This is how a caller keeps the tower's state at a
+ * tap layer -- CLIP.encode_image(image, out_layers), reference model/transformer.py:295-317 -- without copying it:
+ * the tap tensor is the buffer the previous run wrote, the next run writes a fresh one. */
+int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L,
+                     int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* Tap head: ln_post -> seg_proj (Linear no bias [+LeakyReLU]) -> F.normalize, CLS row
  * dropped.  Replaces reference model/adapter.py:171-182.  x [B*L, D] fp32 (tap of the
  * residual stream); proj_w [E, D] dtype; seg_out [B, L-1, E] fp32 unit rows.
