@@ -402,7 +402,7 @@ int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post
   if (det_w) {
     p.W = det_w;
     launch_gemm(dtype, EPI_ACT_F32, p, s);
-    launch_det_mean((const float*)big, (float*)rowf, det_out, B, L, 1, E, s);
+    launch_det_mean((const float*)big, (float*)narrow, (size_t)(big - narrow) / 4, det_out, B, L, 1, E, s);   // narrow is free after the GEMM
   }
   return finish("tap_head");
 }
@@ -420,7 +420,7 @@ int aaclip_det_head(const float* x, const float* ln_post_w, const float* ln_post
   memset(&p, 0, sizeof(p));
   p.A = narrow; p.lda = D; p.W = det_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
   launch_gemm(dtype, EPI_ACT_F32, p, s);
-  launch_det_mean((const float*)big, (float*)rowf, det_out, B, L, 1, E, s);
+  launch_det_mean((const float*)big, (float*)narrow, (size_t)(big - narrow) / 4, det_out, B, L, 1, E, s);
   return finish("det_head");
 }
 

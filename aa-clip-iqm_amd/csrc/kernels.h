@@ -62,7 +62,8 @@ void launch_embed_text(const int32_t* tokens, const float* table, const float* p
 void launch_gather_rows(int dtype, const void* src, void* dst, const int32_t* tokens, int n, int T, int D, int mode,
                         hipStream_t s);
 void launch_normalize_rows(const float* src, float* dst, int B, int L, int skip, int E, hipStream_t s);
-void launch_det_mean(const float* src, float* rowinv, float* dst, int B, int L, int skip, int E, hipStream_t s);
+void launch_det_mean(const float* src, float* scratch, size_t scratch_floats, float* dst, int B, int L, int skip, int E,
+                     hipStream_t s);
 
 // anomaly map (anomaly_map.hip)
 // mode 0: test-mode map m = (s1 + 1 - s0)/2 -> pre [B, P]; mode 1: raw scores -> [B, 2, P]

@@ -287,48 +287,69 @@ void launch_normalize_rows(const float* src, float* dst, int B, int L, int skip,
   }
 }
 
-// det token: F.normalize rows then mean over the patches of each image,
-// reference model/adapter.py:183-184.  Two kernels: row inverse norms, then a
-// column-parallel mean (fixed summation order -> reproducible).
+// det token (reference model/adapter.py:183-184): mean over the patch rows of the L2-normalised det projections.
+// One pass over src: a workgroup takes one image and one slice of its rows, a wave one row at a time (row in
+// registers: norm by wave reduction, accumulate v / |v|); the four waves are added in LDS and the slice sum is
+// written to part[b][slice][E]; a second tiny kernel adds the slices in a fixed order (deterministic).
 template <int NCH>
-__global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restrict__ src, float* __restrict__ inv,
-                                                          long rows) {
+__global__ __launch_bounds__(256) void det_partial_kernel(const float* __restrict__ src, float* __restrict__ part, int L,
+                                                          int skip, int rows_per_slice) {
   constexpr int E = NCH * 256;
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  f32x4 v[NCH];
-  load_row<NCH>(src + row * E, lane, v);
-  float q = 0.f;
+  __shared__ float red[4][E];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int t0 = skip + sl * rows_per_slice;
+  const int t1 = min(L, t0 + rows_per_slice);
+  f32x4 acc[NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int c = 0; c < NCH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = t0 + wave; t < t1; t += 4) {
+    f32x4 v[NCH];
+    load_row<NCH>(src + ((long)b * L + t) * E, lane, v);
+    float q = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) q = fmaf(v[c][e], v[c][e], q);
-  const float n = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
-  if (lane == 0) inv[row] = 1.0f / n;
-}
-__global__ void det_mean_kernel(const float* __restrict__ src, const float* __restrict__ inv, float* __restrict__ dst,
-                                int L, int skip, int E) {
-  const int b = blockIdx.y;
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= E) return;
-  float acc = 0.f;
-  for (int t = skip; t < L; ++t) {
-    const long row = (long)b * L + t;
-    acc += src[row * E + col] * inv[row];
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q = fmaf(v[c][e], v[c][e], q);
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);   // F.normalize eps
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(v[c][e], inv, acc[c][e]);
   }
-  dst[(long)b * E + col] = acc / (float)(L - skip);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) *(f32x4*)&red[wave][(c * 64 + lane) * 4] = acc[c];
+  __syncthreads();
+  for (int i = threadIdx.x; i < E; i += 256)
+    part[((long)b * gridDim.x + sl) * E + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
-void launch_det_mean(const float* src, float* rowinv, float* dst, int B, int L, int skip, int E, hipStream_t s) {
-  const long rows = (long)B * L;
-  dim3 g((unsigned)((rows + 3) / 4));
+__global__ void det_finish_kernel(const float* __restrict__ part, float* __restrict__ dst, int slices, int E, float inv_n) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < E; i += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < slices; ++s) a += part[((long)b * slices + s) * E + i];
+    dst[(long)b * E + i] = a * inv_n;
+  }
+}
+// scratch holds B * slices * E floats; the slice count adapts to scratch_floats
+void launch_det_mean(const float* src, float* scratch, size_t scratch_floats, float* dst, int B, int L, int skip, int E,
+                     hipStream_t s) {
+  const int n = L - skip;
+  int slices = 2048 / B;
+  slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+  if (slices > n) slices = n;
+  const size_t fit = scratch_floats / ((size_t)B * E);
+  if ((size_t)slices > fit) slices = fit < 1 ? 1 : (int)fit;
+  const int rps = (n + slices - 1) / slices;
+  slices = (n + rps - 1) / rps;
+  dim3 g(slices, B);
   switch (E / 256) {
-    case 1: hipLaunchKernelGGL(row_invnorm_kernel<1>, g, dim3(256), 0, s, src, rowinv, rows); break;
-    case 2: hipLaunchKernelGGL(row_invnorm_kernel<2>, g, dim3(256), 0, s, src, rowinv, rows); break;
-    case 3: hipLaunchKernelGGL(row_invnorm_kernel<3>, g, dim3(256), 0, s, src, rowinv, rows); break;
-    case 4: hipLaunchKernelGGL(row_invnorm_kernel<4>, g, dim3(256), 0, s, src, rowinv, rows); break;
+    case 1: hipLaunchKernelGGL(det_partial_kernel<1>, g, dim3(256), 0, s, src, scratch, L, skip, rps); break;
+    case 2: hipLaunchKernelGGL(det_partial_kernel<2>, g, dim3(256), 0, s, src, scratch, L, skip, rps); break;
+    case 3: hipLaunchKernelGGL(det_partial_kernel<3>, g, dim3(256), 0, s, src, scratch, L, skip, rps); break;
+    case 4: hipLaunchKernelGGL(det_partial_kernel<4>, g, dim3(256), 0, s, src, scratch, L, skip, rps); break;
   }
-  hipLaunchKernelGGL(det_mean_kernel, dim3((E + 63) / 64, B), dim3(64), 0, s, src, rowinv, dst, L, skip, E);
+  hipLaunchKernelGGL(det_finish_kernel, dim3(B), dim3(256), 0, s, scratch, dst, slices, E, 1.0f / (float)n);
 }
 
 }  // namespace aaclip
