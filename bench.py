@@ -200,7 +200,7 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": traffic_from_profile(args.precision, B),
+                **traffic_fields(args.precision, B),
                 "launches_timed": len(fc_ms),
                 "avg_launch_ms": round(fc_avg, 4),
                 "flop_per_launch": fc_flop,
@@ -215,21 +215,21 @@ def main():
         dist.destroy_process_group()
 
 
-def traffic_from_profile(precision, batch):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (rocprofv3 --pmc
+def traffic_fields(precision, batch):
+    """`traffic` = HBM bytes per launch of the dominant kernel from the PMC counters (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950), measured offline on this kernel and shape and committed under
     profiles/; null when the committed measurement does not match this run's configuration."""
-    path = os.path.join(REPO, "profiles", "r01d_cfc_gemm_traffic.json")
+    rel = "profiles/r01d_cfc_gemm_traffic.json"
     try:
-        with open(path) as f:
+        with open(os.path.join(REPO, rel)) as f:
             t = json.load(f)
     except OSError:
-        return None
+        return {"traffic": None}
     if precision != "fp16" or t.get("shape") != [batch * 1370, 4096, 1024]:
-        return None
-    return {"bytes": t["traffic_bytes_per_launch"], "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
-            "source": "profiles/r01d_cfc_gemm_traffic.json"}
+        return {"traffic": None}
+    return {"traffic": round(t["traffic_bytes_per_launch"]), "traffic_unit": "bytes per launch",
+            "algorithmic_bytes": t["algorithmic_bytes_per_launch"], "traffic_source": rel}
 
 
 def cpu_baseline(cfg, workload):
