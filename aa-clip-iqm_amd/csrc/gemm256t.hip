@@ -64,44 +64,56 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
         }
       }
     }
+    // per-column vectors of this lane's four column groups
+    f32x4 bv[4], sv[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int nl = ni * 16 + 4 * q4;   // local column of this lane's 4 values
-      const f32x4 bv = *(const f32x4*)(p.bias + n_base + nl);
-      f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-      if (fold) sv = *(const f32x4*)(p.col_s + n_base + nl);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        if (fold) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[mi][ni][j] = fmaf(ab[mi][0], acc[mi][ni][j], ab[mi][1] * sv[j]);
-        }
-        vec4 o;
-        if (EPI == EPI_BIAS_GELU) {
-          f32x2 g0 = {acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]};
-          f32x2 g1 = {acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]};
-          g0 = gelu_fast2(g0);
-          g1 = gelu_fast2(g1);
-          o[0] = from_float<T>(g0[0]); o[1] = from_float<T>(g0[1]);
-          o[2] = from_float<T>(g1[0]); o[3] = from_float<T>(g1[1]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = acc[mi][ni][j] + bv[j];
-            if (n_base + nl + j < p.scale_cols) v *= p.scale;
-            o[j] = from_float<T>(v);
-          }
-        }
-        const int m = mi * 16 + c16;
-        *(vec4*)(st + m * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
-      }
+      bv[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + 4 * q4);
+      sv[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (fold) sv[ni] = *(const f32x4*)(p.col_s + n_base + ni * 16 + 4 * q4);
     }
+    // four passes of 32 rows: convert (GELU) + stage + store one pass, then the next, so that the stores of a
+    // pass drain while the VALU works on the following one (all CUs reach this point together and the stores
+    // are bandwidth-bound: computing everything first and storing afterwards serialises the two)
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int m = it * 8 + (lane >> 3), c = lane & 7;
-      const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
-      const int row = m_base + m;
-      if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int nl = ni * 16 + 4 * q4;   // local column of this lane's 4 values
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int mi = 2 * pass + hh;
+          if (fold) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mi][ni][j] = fmaf(ab[mi][0], acc[mi][ni][j], ab[mi][1] * sv[ni][j]);
+          }
+          vec4 o;
+          if (EPI == EPI_BIAS_GELU) {
+            f32x2 g0 = {acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]};
+            f32x2 g1 = {acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]};
+            g0 = gelu_fast2(g0);
+            g1 = gelu_fast2(g1);
+            o[0] = from_float<T>(g0[0]); o[1] = from_float<T>(g0[1]);
+            o[2] = from_float<T>(g1[0]); o[3] = from_float<T>(g1[1]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[mi][ni][j] + bv[ni][j];
+              if (n_base + nl + j < p.scale_cols) v *= p.scale;
+              o[j] = from_float<T>(v);
+            }
+          }
+          const int m = mi * 16 + c16;
+          *(vec4*)(st + m * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
+        }
+      }
+#pragma unroll
+      for (int it = 4 * pass; it < 4 * pass + 4; ++it) {
+        const int m = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
+        const int row = m_base + m;
+        if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
+      }
     }
   } else {
     // fp32 outputs.  In the accumulator layout the 16 lanes of a quarter-wave hold 16 different rows, i.e. one
