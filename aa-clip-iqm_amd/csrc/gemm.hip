@@ -27,7 +27,7 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
     if (col < p.scale_cols) v *= p.scale;
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
   } else if (EPI == EPI_BIAS_GELU) {
-    // 16-bit outputs: the A&S erf (error far below the output rounding), same in every 16-bit kernel so that
+    // 16-bit outputs: the polynomial erf of common.h (error far below the output rounding), same in every 16-bit kernel so that
     // results do not depend on which tile size a batch selects; fp32 keeps erff
     v = sizeof(TOut) == 4 ? gelu_erf(v + p.bias[col]) : gelu_fast(v + p.bias[col]);
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
