@@ -13,13 +13,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA(i) acc[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i) & 1], b[((i) >> 1) & 1], acc[(i) & 3], 0, 0, 0);
+#define MFMA_A(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[(i) & 3]) : "v"(a[(i) & 1]), "v"(b[((i) >> 1) & 1]));
 #define VALU2(j)                                               \
   v[(j) & 15] = __builtin_amdgcn_exp2f(v[(j) & 15]);            \
   w[(j) & 15] = __builtin_fmaf(w[(j) & 15], 0.999f, v[(j) & 15]); \
   w[((j) + 5) & 15] = __builtin_fmaf(w[((j) + 5) & 15], 1.001f, -0.5f);
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k(const _Float16* in, float* out, int iters) {
+__global__ __launch_bounds__(MODE >= 5 ? 512 : 256, 2) void k(const _Float16* in, float* out, int iters) {
   f16x8 a[2], b[2];
   for (int i = 0; i < 2; ++i) a[i] = *(const f16x8*)(in + ((threadIdx.x * 8 + i) % 4096) * 8);
   for (int i = 0; i < 2; ++i) b[i] = *(const f16x8*)(in + ((threadIdx.x * 4 + i + 77) % 4096) * 8);
@@ -37,6 +38,32 @@ __global__ __launch_bounds__(256, 2) void k(const _Float16* in, float* out, int 
 #pragma unroll
       for (int j = 0; j < 64; ++j) { VALU2(j) }
     }
+    if (MODE == 4) {   // as mode 2 with the accumulators in AGPRs
+#pragma unroll
+      for (int i = 0; i < 32; ++i) MFMA_A(i)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 64; ++j) { VALU2(j) }
+    }
+    if (MODE == 5 || MODE == 6) {   // barrier-synchronised anti-phase: waves 0-3 MFMA while waves 4-7 VALU, then swap
+      const bool first = (threadIdx.x >> 8) == 0;
+      if (first) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { if (MODE == 5) { MFMA(i) } else { MFMA_A(i) } }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) { VALU2(j) }
+      }
+      __builtin_amdgcn_s_barrier();
+      if (!first) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { if (MODE == 5) { MFMA(i) } else { MFMA_A(i) } }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) { VALU2(j) }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
     if (MODE == 3) {
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
@@ -52,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void k(const _Float16* in, float* out, int 
   float s = 0;
   for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][9];
   for (int i = 0; i < 16; ++i) s += v[i] + w[i];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[(blockIdx.x * 512 + threadIdx.x) % (1024 * 256)] = s;
 }
 
 int main() {
@@ -65,17 +92,22 @@ int main() {
   hipMemcpy(d, h, n * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 2000;
-  const char* names[4] = {"MFMA only", "VALU only", "MFMA block then VALU block", "interleaved in one wave"};
+  const char* names[7] = {"MFMA only", "VALU only", "MFMA block then VALU block", "interleaved in one wave",
+                          "block then block, AGPR accumulators", "anti-phase by barrier (8-wave WG)", "anti-phase by barrier, AGPR acc"};
   for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu)
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
+      if (mode >= 5 && wg_per_cu == 2) continue;   // the 8-wave workgroup already puts 2 waves on every SIMD
       float best = 1e9;
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        const dim3 g(256 * wg_per_cu), b(256);
+        const dim3 g(256 * wg_per_cu), b(mode >= 5 ? 512 : 256);
         if (mode == 0) hipLaunchKernelGGL(k<0>, g, b, 0, 0, d, o, iters);
         if (mode == 1) hipLaunchKernelGGL(k<1>, g, b, 0, 0, d, o, iters);
         if (mode == 2) hipLaunchKernelGGL(k<2>, g, b, 0, 0, d, o, iters);
         if (mode == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, d, o, iters);
+        if (mode == 4) hipLaunchKernelGGL(k<4>, g, b, 0, 0, d, o, iters);
+        if (mode == 5) hipLaunchKernelGGL(k<5>, g, b, 0, 0, d, o, iters);
+        if (mode == 6) hipLaunchKernelGGL(k<6>, g, b, 0, 0, d, o, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
