@@ -737,274 +737,6 @@ __global__ __launch_bounds__(256, 2) void attn16p_kernel(const T* __restrict__ q
   }
 }
 
-// ---------------------------------------------------------------------------
-// Attention variant 6: software pipeline inside each wave.  tools/valu_mfma_overlap.hip and the anti-phase
-// experiment show that on this chip VALU work hides in the shadow of the SAME wave's MFMAs (an MFMA
-// holds the vector issue for 8 of its 32 cycles), hardly in a neighbouring wave's.  So every wave interleaves, per
-// key tile t: the 16 score MFMAs of tile t+1 with the exponentials / sums / conversions of tile t, then the 16
-// P(t).V(t) MFMAs with the maxima of tile t+1.  Two query blocks per wave as in attn16x2_kernel; Q lives in LDS
-// (K-tile layout, private to the wave) so that both score tiles fit in 256 registers; one 8-wave workgroup per CU.
-template <typename T, bool LOG2Q>
-__global__ __launch_bounds__(512, 2) void attn16w_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
-                                                         int causal) {
-  typedef typename Elem<T>::vec8 vec8;
-  typedef typename Elem<T>::vec4 vec4;
-  typedef short i16x8 __attribute__((ext_vector_type(8)));
-  __shared__ __attribute__((aligned(16))) char smem[65536 + 65536];  // 4 stages x (K 8K + V 8K), then Q: 8 waves x 8K
-  constexpr float LOG2E = 1.4426950408889634f;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  const int D = H * 64;
-  const long ld = 3L * D;
-  const T* base = qkv + (long)b * L * ld + head * 64;
-  const int q0 = qt * 512 + wave * 64;
-  const bool active = q0 < L;   // wave-uniform: idle waves only feed the ring and the barriers
-
-  char* qs = smem + 65536 + wave * 8192;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int slot = j * 64 + lane, row = slot >> 3, sl = slot & 7;
-    int qrow = q0 + row;
-    qrow = qrow < L ? qrow : L - 1;
-    glds16(base + (long)qrow * ld + (sl ^ xk(row)) * 8, qs + j * 1024);
-  }
-  const int prow = (wave * 64 + lane) >> 3, psl = lane & 7;
-  const T* ksrc = base + (long)prow * ld + D + (psl ^ xk(prow)) * 8;
-  const T* vsrc = base + (long)prow * ld + 2 * D + (psl ^ xv(prow)) * 8;
-  int koff[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ xk(r)) << 4);
-  int voff[2];
-  {
-    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
-    const int row = 4 * (g >> 1) + qq;
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
-      voff[db] = 8192 + row * 128 + ((chunk ^ xv(row)) << 4) + (pp & 1) * 8;
-    }
-  }
-  int last_q = qt * 512 + 511;
-  if (last_q > L - 1) last_q = L - 1;
-  const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
-
-  auto stage = [&](int st, int kt) {
-    char* dst = smem + st * 16384 + wave * 1024;
-    const long step = (long)kt * 64 * ld;
-    int over = kt * 64 + prow - (L - 1);
-    over = over > 0 ? over : 0;   // rows past the end re-read row L-1 (masked later)
-    glds16(ksrc + step - (long)over * ld, dst);
-    glds16(vsrc + step - (long)over * ld, dst + 8192);
-  };
-
-  f32x16 o[2][2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[qb][db][e] = 0.f;
-  float m2[2] = {0.f, 0.f}, l[2] = {0.f, 0.f}, mt[2] = {0.f, 0.f};
-
-  // scaling for the non-log2 contract, tail / causal masks (edge tiles only), tile maxima
-  auto finish_scores = [&](f32x16 (&s)[2][2], int kt) {
-    if (!LOG2Q) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[qb][sub][e] = fmaf(s[qb][sub][e], LOG2E, -m2[qb]);
-    }
-    const int k0 = kt * 64;
-    const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));
-    if (need_mask) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            int key = k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            bool dead = (key >= L) || (causal && key > q0 + qb * 32 + r);
-            s[qb][sub][e] = dead ? -INFINITY : s[qb][sub][e];
-          }
-    }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float a = s[qb][0][0], c = s[qb][1][0];
-#pragma unroll
-      for (int e = 1; e < 16; ++e) {
-        a = fmaxf(a, s[qb][0][e]);
-        c = fmaxf(c, s[qb][1][e]);
-      }
-      a = fmaxf(a, c);
-      mt[qb] = fmaxf(a, __shfl_xor(a, 32, 64));
-    }
-  };
-
-  auto rebase = [&](f32x16 (&s)[2][2], bool first) {
-    if (first || __any(fmaxf(mt[0], mt[1]) > 0.f)) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-        m2[qb] += delta;
-        l[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[qb][sub][e] -= delta;
-      }
-    }
-  };
-
-  vec8 pf[2][2][2];   // P(t) as MFMA operands: [qb][sub][s2]
-
-// slice ks of step t: 4 score MFMAs of tile t+1 (K slice ks) + the exponentials of a quarter of tile t
-// (sub = ks >> 1, s2 = ks & 1: 8 values per lane and query block)
-#define W_QK_EXP(SBN, SNEXT, SCUR, WITH_QK)                                                         \
-  {                                                                                                 \
-    float rs[2] = {0.f, 0.f};                                                                       \
-    if (WITH_QK) {                                                                                  \
-      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                              \
-        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub)                                         \
-          _Pragma("unroll") for (int e = 0; e < 16; ++e) SNEXT[qb][sub][e] = LOG2Q ? -m2[qb] : 0.f; \
-    }                                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                              \
-      if (WITH_QK) {                                                                                \
-        const vec8 k0f = *(const vec8*)((SBN) + koff[ks]);                                          \
-        const vec8 k1f = *(const vec8*)((SBN) + koff[ks] + 4096);                                   \
-        const vec8 q0f = *(const vec8*)(qs + koff[ks]);                                             \
-        const vec8 q1f = *(const vec8*)(qs + koff[ks] + 4096);                                      \
-        SNEXT[0][0] = Elem<T>::mma32(k0f, q0f, SNEXT[0][0]);                                        \
-        SNEXT[1][0] = Elem<T>::mma32(k0f, q1f, SNEXT[1][0]);                                        \
-        SNEXT[0][1] = Elem<T>::mma32(k1f, q0f, SNEXT[0][1]);                                        \
-        SNEXT[1][1] = Elem<T>::mma32(k1f, q1f, SNEXT[1][1]);                                        \
-      }                                                                                             \
-      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
-          const float pe = __builtin_amdgcn_exp2f(SCUR[qb][ks >> 1][8 * (ks & 1) + j]);             \
-          rs[qb] += pe;                                                                             \
-          pf[qb][ks >> 1][ks & 1][j] = from_float<T>(pe);                                           \
-        }                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                            \
-    }                                                                                               \
-    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) l[qb] += rs[qb] + __shfl_xor(rs[qb], 32, 64);  \
-  }
-
-  auto pv = [&](const char* sb) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        vec8 vf[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
-          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
-          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
-          i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          vf[db] = __builtin_bit_cast(vec8, both);
-        }
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          o[qb][0] = Elem<T>::mma32(vf[0], pf[qb][sub][s2], o[qb][0]);
-          o[qb][1] = Elem<T>::mma32(vf[1], pf[qb][sub][s2], o[qb][1]);
-        }
-      }
-  };
-
-  // ring prologue: Q (8 DMA pieces) and up to three key tiles in flight; Q and tile 0 visible
-  stage(0, 0);
-  if (nkt > 1) stage(1, 1);
-  if (nkt > 2) stage(2, 2);
-  if (nkt > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (nkt > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  f32x16 sA[2][2], sB[2][2];
-  if (active) {   // S(0), not pipelined
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sA[qb][sub][e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          sA[qb][sub] = Elem<T>::mma32(*(const vec8*)(smem + koff[ks] + sub * 4096),
-                                        *(const vec8*)(qs + koff[ks] + qb * 4096), sA[qb][sub]);
-      }
-    finish_scores(sA, 0);
-  }
-
-// key tile t that has a successor: SCUR holds S'(t); S'(t+1) goes to SNEXT while SCUR is exponentiated
-#define WPIPE_STEP(t, SCUR, SNEXT)                                                 \
-  {                                                                                \
-    /* make tile t+1 visible, free the stage of tile t-1 */                        \
-    if ((t) + 2 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
-    __builtin_amdgcn_s_barrier();                                                  \
-    if ((t) + 3 < nkt) stage(((t) + 3) & 3, (t) + 3);                              \
-    if (active) {                                                                  \
-      rebase(SCUR, (t) == 0);                                                      \
-      W_QK_EXP(smem + (((t) + 1) & 3) * 16384, SNEXT, SCUR, true)                  \
-      pv(smem + ((t) & 3) * 16384);                                                \
-      finish_scores(SNEXT, (t) + 1);                                               \
-    }                                                                              \
-  }
-  int t = 0;
-  for (; t + 2 < nkt; t += 2) {   // two tiles per trip: the score buffers swap roles and are back in place
-    WPIPE_STEP(t, sA, sB)
-    WPIPE_STEP(t + 1, sB, sA)
-  }
-  const bool odd_tail = t + 1 < nkt;   // one more tile with a successor
-  if (odd_tail) WPIPE_STEP(t, sA, sB)
-  if (active) {  // last tile (no successor): its scores sit in sB after an odd tail step, else in sA
-    const int tl = nkt - 1;
-    const char* sb = smem + (tl & 3) * 16384;
-    if (odd_tail) {
-      rebase(sB, tl == 0);
-      W_QK_EXP(smem, sA, sB, false)
-    } else {
-      rebase(sA, tl == 0);
-      W_QK_EXP(smem, sB, sA, false)
-    }
-    pv(sb);
-  }
-#undef WPIPE_STEP
-#undef W_QK_EXP
-
-  if (active) {
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qi = q0 + qb * 32 + r;
-      if (qi < L) {
-        const float inv = 1.0f / l[qb];
-        T* dst = ctx + ((long)b * L + qi) * D + head * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
-            vec4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = from_float<T>(o[qb][db][4 * gi + j] * inv);
-            *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = v;
-          }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------ fp32 path
 __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L,
                                                      int H, int causal) {
@@ -1116,15 +848,6 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
     } else {
       if (log2q) hipLaunchKernelGGL((attn16p_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
       else hipLaunchKernelGGL((attn16p_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
-    }
-  } else if (L >= 512 && g_attn_variant == 6) {   // software pipeline inside each wave, 8 waves, Q in LDS
-    dim3 g((L + 511) / 512, H, B);
-    if (dtype == AACLIP_F16) {
-      if (log2q) hipLaunchKernelGGL((attn16w_kernel<f16, true>), g, dim3(512), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
-      else hipLaunchKernelGGL((attn16w_kernel<f16, false>), g, dim3(512), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
-    } else {
-      if (log2q) hipLaunchKernelGGL((attn16w_kernel<bf16, true>), g, dim3(512), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
-      else hipLaunchKernelGGL((attn16w_kernel<bf16, false>), g, dim3(512), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
     }
   } else if (L >= 512 && g_attn_variant != 1) {
     dim3 g((L + 255) / 256, H, B);
