@@ -177,3 +177,33 @@ def test_checkpoint_loading_state_dict_and_torchscript(tmp_path, monkeypatch):
     monkeypatch.setenv("AACLIP_CLIP_CKPT", jit)
     with pytest.raises(RuntimeError):
         create_model("ViT-L-14-336", 518, pretrained="openai")
+
+
+def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
+    """Regression guard for a silent 15 % loss: when hipcc cannot prove the K loop's buffer descriptors
+    wave-uniform it wraps every `buffer_load ... lds` in a waterfall loop (v_readfirstlane x4 + s_and_saveexec).
+    The default GEMM kernel's K loop (between its first and last s_barrier) must contain neither."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(REPO, "aa-clip-iqm_amd", "csrc", "gemm256t.hip")
+    out = str(tmp_path / "gemm256t.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    checked = 0
+    for epi in range(5):
+        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}EEEvNS_10GemmParamsEiiiii:"
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
+        body = lines[start:end]
+        bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+        loop = [l.split()[0] for l in body[bars[0]:bars[-1]] if l.strip() and not l.strip().startswith((".", ";"))]
+        assert loop.count("buffer_load_dwordx4") >= 16, (epi, "K loop not found")
+        assert "v_readfirstlane_b32" not in loop and "s_and_saveexec_b64" not in loop, \
+            f"EPI {epi}: waterfall loop around the K-loop DMA (descriptor not provably uniform)"
+        assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi}: spill in the K loop"
+        checked += 1
+    assert checked == 5
