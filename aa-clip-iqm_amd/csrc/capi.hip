@@ -479,13 +479,20 @@ int aaclip_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const in
   REQUIRE(S >= 1 && S <= 4096, "preprocess: output size must be 1..4096");
   // largest tile height whose source rectangle (rows x pitch bytes) and horizontally resampled rows
   // (rows x 64 columns x 3 planes) fit in 60 KiB of LDS
-  const int pitch = preprocess_row_pitch(Ws, S);
+  int pitch = preprocess_row_pitch(Ws, S);
   int ty = 16, rows = 0;
-  for (; ty >= 1; ty >>= 1) {
+  for (; ty >= 2; ty >>= 1) {
     rows = preprocess_tile_rows(Hs, S, ty);
     if ((size_t)rows * (pitch + 3 * 64) <= 60 * 1024) break;
   }
-  REQUIRE(ty >= 1, "preprocess: source too large for one output row of a tile to fit in LDS");
+  if (ty < 2) {   // very large frames (downscale beyond ~6x): no LDS copy of the source, pass 1 gathers from global memory
+    pitch = 0;
+    for (ty = 16; ty >= 1; ty >>= 1) {
+      rows = preprocess_tile_rows(Hs, S, ty);
+      if ((size_t)rows * 3 * 64 <= 60 * 1024) break;
+    }
+  }
+  REQUIRE(ty >= 1, "preprocess: source too tall for one output row to fit in LDS (downscale beyond ~100x)");
   launch_preprocess(src, B, Hs, Ws, S, hbounds, hcoefs, resample_ksize(Ws, S), vbounds, vcoefs, resample_ksize(Hs, S),
                     ty, rows, pitch, lut, out, (hipStream_t)stream);
   return finish("preprocess");

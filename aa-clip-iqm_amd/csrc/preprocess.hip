@@ -96,6 +96,7 @@ AACLIP_DEV int clip8(int acc) {
 
 // grid (ceil(S/64), ceil(S/TY), B), 256 threads.  Dynamic LDS: [lds_rows][pitch] source bytes (16-byte
 // aligned segments copied with 16-byte loads), then [3][lds_rows][64] uint8 planes of the horizontal pass.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ src, int Hs, int Ws, int S,
                                                          const int32_t* __restrict__ hb, const int32_t* __restrict__ hk,
                                                          int kx, const int32_t* __restrict__ vb,
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ float s_lut[3 * 256];
   uint8_t* stage = lds;
-  uint8_t* tmp = lds + (size_t)lds_rows * pitch;
+  uint8_t* tmp = lds + (STAGE ? (size_t)lds_rows * pitch : 0);   // !STAGE: no source copy, pass 1 reads global memory
   const int x0 = blockIdx.x * PP_TX, y0 = blockIdx.y * TY, b = blockIdx.z;
   const int ny = min(TY, S - y0), nx = min(PP_TX, S - x0);
   for (int i = threadIdx.x; i < 3 * 256; i += 256) s_lut[i] = lut[i];
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
   // pass 0: source rows r0 .. r0+R-1, byte range [c0*3, c1*3) of each, into LDS; a row's segment starts at
   // its 16-byte aligned global address, so the first `shift` bytes of the LDS row are padding
   const int chunks = pitch >> 4;
-  for (int i = threadIdx.x; i < R * chunks; i += 256) {
+  for (int i = threadIdx.x; STAGE && i < R * chunks; i += 256) {
     const int r = i / chunks, ch = i - r * chunks;
     const long a0 = img0 + ((long)(r0 + r) * Ws + c0) * 3;
     const long a = (a0 & ~15L) + ch * 16;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     const int first = hb[2 * x], n = hb[2 * x + 1];
     const int32_t* k = hk + (size_t)x * kx;
     const int shift = (int)((img0 + ((long)(r0 + r) * Ws + c0) * 3) & 15);
-    const uint8_t* p = stage + r * pitch + shift + (first - c0) * 3;
+    const uint8_t* p = STAGE ? stage + r * pitch + shift + (first - c0) * 3
+                             : src + img0 + ((long)(r0 + r) * Ws + first) * 3;
     int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
     for (int t = 0; t < n; ++t) {
       const int w = k[t];
@@ -183,9 +185,15 @@ void launch_preprocess(const uint8_t* src, int B, int Hs, int Ws, int S, const i
                        const int32_t* vb, const int32_t* vk, int ky, int TY, int lds_rows, int pitch, const float* lut,
                        float* out, hipStream_t s) {
   dim3 grid((S + PP_TX - 1) / PP_TX, (S + TY - 1) / TY, B);
-  const size_t lds = (size_t)lds_rows * pitch + (size_t)3 * lds_rows * PP_TX;
-  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), lds, s, src, Hs, Ws, S, hb, hk, kx, vb, vk, ky, TY, lds_rows,
-                     pitch, (long)B * Hs * Ws * 3, lut, out);
+  if (pitch > 0) {
+    const size_t lds = (size_t)lds_rows * pitch + (size_t)3 * lds_rows * PP_TX;
+    hipLaunchKernelGGL(preprocess_kernel<true>, grid, dim3(256), lds, s, src, Hs, Ws, S, hb, hk, kx, vb, vk, ky, TY,
+                       lds_rows, pitch, (long)B * Hs * Ws * 3, lut, out);
+  } else {   // pitch 0: the source rectangle of a tile does not fit in LDS (very large frames); gather from global memory
+    const size_t lds = (size_t)3 * lds_rows * PP_TX;
+    hipLaunchKernelGGL(preprocess_kernel<false>, grid, dim3(256), lds, s, src, Hs, Ws, S, hb, hk, kx, vb, vk, ky, TY,
+                       lds_rows, 0, (long)B * Hs * Ws * 3, lut, out);
+  }
 }
 
 }  // namespace aaclip

@@ -94,7 +94,9 @@ def test_gemm_exact_integers(dev, code):
 
 
 @pytest.mark.parametrize("code", [F32, F16, BF16])
-@pytest.mark.parametrize("shape", [(1370, 1024, 1024), (300, 128, 64), (77, 768, 3072), (129, 384, 640)])
+@pytest.mark.parametrize("shape", [(1370, 1024, 1024), (300, 128, 64), (77, 768, 3072), (129, 384, 640),
+                                   (4100, 256, 192),     # large M, odd K/64: the fallback 256-tile kernel
+                                   (5000, 768, 1024)])   # large M, ragged last tile: the default 256-tile kernel
 def test_gemm_epilogues(dev, code, shape):
     lib = _lib.load()
     M, N, K = shape
@@ -461,7 +463,8 @@ def test_auroc_parity_on_synthetic_masks(dev, full_weights):
 # ----------------------------------------------------------------------------
 @pytest.mark.parametrize("h,w,s,B", [(96, 96, 70, 2), (150, 130, 70, 3), (40, 56, 70, 1), (70, 70, 70, 2),
                                      (70, 100, 70, 1), (301, 70, 70, 1), (700, 700, 518, 2), (1024, 1024, 518, 2),
-                                     (256, 300, 518, 1), (2500, 900, 518, 1), (5, 3, 70, 1)])
+                                     (256, 300, 518, 1), (2500, 900, 518, 1), (5, 3, 70, 1),
+                                     (1400, 1450, 70, 1)])   # 20x downscale: the source tile does not fit in LDS
 def test_preprocess_bit_exact(dev, h, w, s, B):
     from oracle import preprocess_oracle as P
     rng = np.random.default_rng(h * 31 + w)
