@@ -700,3 +700,24 @@ def test_tiny_adapted_large_batch_vs_oracle(dev, code):
     assert_close(pooled, opooled, s4 * atol, rtol, "pooled (B=160)")
     for i in range(2):
         assert_close(taps[i], otaps[i], s4 * atol, rtol, f"tap{i} (B=160)")
+
+
+def test_bench_batch_is_bit_identical_to_small_large_regime_batches(dev, full_weights):
+    """BASELINE.json's size (B = 64) through a size-independent property: every image's seg / det tokens and
+    anomaly map at B = 64 are bit-identical to what a batch of 4 gives (same kernels), which the other tests tie to
+    the oracle and the reference's golden vectors."""
+    import forward_utils as FU
+    model = build_full(dev, "fp16", full_weights)
+    img = synth.synth_images(64, 518, seed=64).to(dev)
+    anchors = torch.nn.functional.normalize(synth.randn("t.b64.anchors", (768, 2), 1.0, 3), dim=0).to(dev)
+    with torch.no_grad():
+        seg, det, _ = model(img)
+        amap = FU.calculate_anomaly_map(seg, anchors, 518, domain="Industrial")
+        for lo in (0, 60):
+            seg4, det4, _ = model(img[lo:lo + 4])
+            amap4 = FU.calculate_anomaly_map(seg4, anchors, 518, domain="Industrial")
+            for a, b in zip(seg, seg4):
+                assert torch.equal(a[lo:lo + 4], b)
+            assert torch.equal(det[lo:lo + 4], det4)
+            assert torch.equal(amap[lo:lo + 4], amap4)
+    assert torch.isfinite(amap).all()
