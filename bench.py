@@ -134,7 +134,8 @@ def main():
         dt = float(tmax.item())
 
         extra = {}
-        if rank == 0 and not args.no_extra:
+        if not args.no_extra:
+            # (every rank runs these untimed steps: step() ends in the all-gather, a collective all ranks must enter)
             # per-kernel-class breakdown of one extra (untimed) step
             cap2 = 8 * 24 + 16
             _lib.check(lib.aaclip_profile_begin(0x7F, cap2), "profile_begin")
