@@ -59,8 +59,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal on a one-GPU box: AACLIP_BENCH_BACKEND=gloo puts all ranks on the visible device(s) and runs the
+        # same control flow (barriers, max-over-ranks, the all-gather) without RCCL, which refuses two ranks per GPU
+        backend = os.environ.get("AACLIP_BENCH_BACKEND", "nccl")
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
