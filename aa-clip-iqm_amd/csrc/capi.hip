@@ -201,10 +201,6 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
   return finish("patch_embed");
 }
 
-// what the aux region holds for the next block's folded ln_1: nothing, the final (rstd, -mean*rstd) pairs (written by
-// the adapter mix), or the partial row sums of a residual GEMM epilogue (reduced by the consumer)
-enum { AUX_NONE = 0, AUX_ROWAB = 1, AUX_PARTIALS = 2 };
-
 // One block.  aux_in: the aux region of the workspace holds the current rows of x in the compute dtype and their
 // (rstd, -mean*rstd) pairs, written by the previous block of the same aaclip_blocks call -- then ln_1 is folded
 // into the QKV product.  want_out: produce them for the next block (from the c_proj epilogue, or from the adapter
@@ -212,10 +208,9 @@ enum { AUX_NONE = 0, AUX_ROWAB = 1, AUX_PARTIALS = 2 };
 // x_in != x: the block READS the stream from x_in (left untouched) and continues it in x -- the first residual
 // update (out_proj) takes its residual from x_in and writes x.
 static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H,
-                      int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, hipStream_t s, int aux_in,
-                      bool want_out, int* aux_out) {
-  *aux_out = AUX_NONE;
-  const bool aux_partials = aux_in == AUX_PARTIALS;
+                      int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, hipStream_t s, bool aux_in,
+                      bool want_out, bool* aux_out) {
+  *aux_out = false;
   REQUIRE(w->ln1_w && w->ln1_b && w->qkv_w && w->qkv_b && w->out_w && w->out_b && w->ln2_w && w->ln2_b && w->fc_w &&
               w->fc_b && w->proj_w && w->proj_b,
           "block: null weight pointer");
@@ -256,13 +251,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     p.ldc = 3 * D; p.scale_cols = D; p.scale = qscale;
     if (aux_in && folding && w->qkv_w_fold && w->qkv_fold_s && w->qkv_fold_b && gemm_routes_to_256t(dtype, p)) {
       // ln_1 folded into the QKV product (include/aaclip.h, aaclip_block_weights)
-      p.A = x16; p.W = w->qkv_w_fold; p.bias = w->qkv_fold_b; p.col_s = w->qkv_fold_s;
-      if (aux_partials && gemm_routes_to_256x(dtype, p) && D % 128 == 0 && D <= 1024) {   // the workgroups reduce the partial sums themselves
-        p.stats_in = partials; p.stats_slots = D / 64; p.stats_inv_d = 1.0f / D; p.stats_eps = 1e-5f;
-      } else {
-        if (aux_partials) { ProfScope ps(0, s); launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s); }
-        p.row_ab = rowab;
-      }
+      p.A = x16; p.W = w->qkv_w_fold; p.bias = w->qkv_fold_b; p.row_ab = rowab; p.col_s = w->qkv_fold_s;
     } else {
       ProfScope ps(0, s);
       launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
@@ -288,14 +277,9 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
   { ProfScope ps(3, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
   // ---- x += c_proj(gelu(c_fc(ln_2 x)))
   if (fold2) {
-    fc.A = x16; fc.W = w->fc_w_fold; fc.bias = w->fc_fold_b; fc.col_s = w->fc_fold_s;
-    if (gemm_routes_to_256x(dtype, fc) && D % 128 == 0 && D <= 1024) {
-      fc.stats_in = partials; fc.stats_slots = D / 64; fc.stats_inv_d = 1.0f / D; fc.stats_eps = 1e-5f;
-    } else {
-      ProfScope ps(0, s);
-      launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s);
-      fc.row_ab = rowab;
-    }
+    ProfScope ps(0, s);
+    launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s);
+    fc.A = x16; fc.W = w->fc_w_fold; fc.bias = w->fc_fold_b; fc.row_ab = rowab; fc.col_s = w->fc_fold_s;
   } else {
     ProfScope ps(0, s);
     launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s);
@@ -311,7 +295,11 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     p.stats_out = partials;
   }
   { ProfScope ps(5, s); launch_gemm(dtype, EPI_BIAS_RESID, p, s); }
-  if (emit && !w->adapter_w) *aux_out = AUX_PARTIALS;   // partial sums in aux; the next block's QKV product reduces them
+  if (emit && !w->adapter_w) {
+    ProfScope ps(0, s);
+    launch_ln_stats_finalize(partials, rowab, rows, D / 64, D, 1e-5f, s);
+    *aux_out = true;
+  }
   // ---- residual adapter
   if (w->adapter_w) {
     ProfScope ps(6, s);
@@ -327,7 +315,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     launch_gemm(dtype, EPI_ACT_F32, p, s);
     if (folding && want_out) {
       launch_adapter_mix_fold(dtype, x, (const float*)big, rows, D, mix, x16, rowab, s);
-      *aux_out = AUX_ROWAB;
+      *aux_out = true;
     } else {
       launch_adapter_mix(x, (const float*)big, rows, D, mix, s);
     }
@@ -357,9 +345,9 @@ int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w,
   const long rows = (long)B * L;
   REQUIRE(rows < (1L << 31) / 4, "block: too many rows");
   REQUIRE(ws_bytes >= aaclip_workspace_bytes(dtype, rows, D, F, 0), "block: workspace too small");
-  int aux = AUX_NONE;
+  bool aux = false;
   for (int i = 0; i < n_blocks; ++i) {
-    int produced = AUX_NONE;
+    bool produced = false;
     int rc = block_impl(i == 0 ? x_in : x, x, w + i, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes,
                         (hipStream_t)stream, aux, i + 1 < n_blocks, &produced);
     if (rc) return rc;

@@ -278,10 +278,6 @@ bool gemm_routes_to_256t(int dtype, const GemmParams& p) {
   return true;
 }
 
-bool gemm_routes_to_256x(int dtype, const GemmParams& p) {
-  return gemm_routes_to_256t(dtype, p) && g_gemm_variant == 0 && ((p.K >> 6) & 1) == 0;
-}
-
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {

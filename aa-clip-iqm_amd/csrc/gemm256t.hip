@@ -38,7 +38,7 @@ AACLIP_DEV float row16_sum(float x) {
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
 template <typename T, int EPI>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane,
-                             const f32x2 (&ab_in)[8], bool ab_valid) {
+                             const f32x2* ab_pre = nullptr) {
   typedef typename Elem<T>::vec4 vec4;
   // Everything the epilogue addresses with is derived from `lane` below this point: the empty asm keeps hipcc from
   // computing it before the K loop and carrying it through (measured: the folding code alone cost the residual
@@ -50,13 +50,13 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
     __syncthreads();  // every wave is done reading the operand tiles
     char* st = smem + wave * 16384;  // this wave's 128 x 64 tile of T: rows of 128 B, 16-B chunk ^= (m & 7)
-    const bool fold = p.row_ab != nullptr || ab_valid;   // LayerNorm folded into this product: acc -> a_m * acc + b_m * s_n
+    const bool fold = p.row_ab != nullptr;   // LayerNorm folded into this product: acc -> a_m * acc + b_m * s_n
     f32x2 ab[8];
     if (fold) {
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
-        if (ab_valid) {
-          ab[mi] = ab_in[mi];   // fetched before the K loop by the caller (their latency is exposed here otherwise)
+        if (ab_pre) {
+          ab[mi] = ab_pre[mi];   // fetched before the K loop by the caller (their latency is exposed here otherwise)
         } else {
           int row = m_base + mi * 16 + c16;
           row = row < p.M ? row : p.M - 1;
@@ -190,12 +190,6 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
       }
     }
   }
-}
-
-template <typename T, int EPI>
-AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane) {
-  const f32x2 none[8] = {};
-  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane, none, false);
 }
 
 template <typename T, int EPI>
@@ -933,7 +927,6 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[131072];
-  __shared__ f32x2 ab_tab[256];   // LayerNorm folding: (rstd, -mean*rstd) of this tile's rows, reduced here from partials
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1003,35 +996,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   // LayerNorm folding: this lane's (rstd, -mean*rstd) pairs, requested now so that they are there at the epilogue
-  f32x2 ab_pre[8] = {};
-  const bool fold_tab = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.stats_in != nullptr;
-  const bool fold_pre = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && (p.row_ab != nullptr || fold_tab);
-  if (fold_tab) {
-    // one thread per row of the tile adds the row's partial (sum, sum of squares) pairs in slot order -- the same
-    // arithmetic as ln_stats_finalize_kernel -- and publishes (rstd, -mean*rstd) through LDS (visible after the
-    // prologue barrier below)
-    if (tid < 256) {
-      int row = tm * 256 + tid;
-      row = row < p.M ? row : p.M - 1;
-      // up to 16 slots (D <= 1024), two per 16-byte load, all loads in flight before the first add
-      const f32x4* pp = (const f32x4*)(p.stats_in + (long)row * p.stats_slots * 2);
-      const int pairs = (p.stats_slots + 1) >> 1;   // stats_slots is even for every supported width
-      f32x4 v4[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v4[i] = i < pairs ? pp[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      float sm = 0.f, sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {   // same order of additions as ln_stats_finalize_kernel (zeros past the end)
-        sm += v4[i][0]; sq += v4[i][1];
-        sm += v4[i][2]; sq += v4[i][3];
-      }
-      const float mean = sm * p.stats_inv_d;
-      float var = sq * p.stats_inv_d - mean * mean;
-      var = var > 0.f ? var : 0.f;
-      const float rstd = rsqrtf(var + p.stats_eps);
-      ab_tab[tid] = (f32x2){rstd, -mean * rstd};
-    }
-  } else if (fold_pre) {
+  f32x2 ab_pre[8];
+  const bool fold_pre = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.row_ab != nullptr;
+  if (fold_pre) {
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       int row = tm * 256 + wr * 128 + mi * 16 + c16;
@@ -1111,10 +1078,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
   BAR
   LD_N(fnX, smem, 0)
-  if (fold_tab) {
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) ab_pre[mi] = ab_tab[wr * 128 + mi * 16 + c16];
-  }
   if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
   for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
     KTILE(kt, fnX, fnY)
@@ -1133,7 +1096,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef MM
 #undef QUADX
 #undef KTILE
-  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane, ab_pre, fold_pre);
+  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
 }
 
 template <typename T>

@@ -28,9 +28,6 @@ struct GemmParams {
   float* stats_out;        // EPI_BIAS_RESID: per row and 64-column slice (sum, sum of squares) of the new rows, [M][N/64][2]
   const float* row_ab;     // EPI_BIAS / EPI_BIAS_GELU: per row (a, b); value = a*acc + b*col_s[n] + bias[n]
   const float* col_s;      //   [N] row sums of the (gamma-scaled) weight
-  const float* stats_in;   //   instead of row_ab (default 256-tile kernel only): the [M][stats_slots][2] partial sums a
-  int stats_slots;         //   residual GEMM wrote; each workgroup reduces its 256 rows itself (no finalize launch)
-  float stats_inv_d, stats_eps;
 };
 
 const char* gemm_check(int dtype, int epi, const GemmParams& p);
@@ -79,8 +76,7 @@ void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
 // LayerNorm folding: [M][slots][2] partial (sum, sumsq) -> [M][2] (rstd, -mean*rstd)
 void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s);
-bool gemm_routes_to_256t(int dtype, const GemmParams& p);
-bool gemm_routes_to_256x(int dtype, const GemmParams& p);   // ... and it is the default kernel (even K/64): accepts stats_in   // launch_gemm will run a kernel with the folding epilogue
+bool gemm_routes_to_256t(int dtype, const GemmParams& p);   // launch_gemm will run a kernel with the folding epilogue
 // V-V "surgery" attention over the batch axis: regroup v [B*L,D] -> packed q|k|v rows l*B+b and back
 void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s);
 void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s);
