@@ -12,6 +12,8 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AACLIP_LIB") or os.path.join(_HERE, "libaaclip_hip.so")   # AACLIP_LIB: experiment builds
+MEASURE_LIB_PATH = os.path.join(_HERE, "libaaclip_hip_measure.so")   # `make measure`: A/B variants, ablations, stamps
+ABI_VERSION = 3   # include/aaclip.h AACLIP_ABI_VERSION this binding was written against
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
@@ -21,17 +23,23 @@ _vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
 
 class BlockWeights(C.Structure):
-    """struct aaclip_block_weights (include/aaclip.h)."""
-    _fields_ = [(n, _vp) for n in (
+    """struct aaclip_block_weights (include/aaclip.h).  struct_bytes is filled in on construction; the library
+    refuses a struct whose size field does not match its own sizeof."""
+    _fields_ = [("struct_bytes", _sz)] + [(n, _vp) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b",
         "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w", "fc_w_fold", "fc_fold_s", "fc_fold_b",
         "qkv_w_fold", "qkv_fold_s", "qkv_fold_b")]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_bytes = C.sizeof(BlockWeights)
 
 
 # name -> (restype, argtypes); every symbol include/aaclip.h declares
 SIGNATURES = {
     "aaclip_version": (_i, []),
     "aaclip_last_error": (C.c_char_p, []),
+    "aaclip_is_measurement_build": (_i, []),
     "aaclip_workspace_bytes": (_sz, [_i, _l, _i, _i, _i]),
     "aaclip_patch_embed": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _sz, _vp]),
     "aaclip_block": (_i, [_vp, C.POINTER(BlockWeights), _f] + [_i] * 7 + [_vp, _sz, _vp]),
@@ -73,9 +81,10 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        v = os.environ.get("AACLIP_GEMM_VARIANT")
-        if v:
-            lib.aaclip_set_gemm_variant(int(v))
+        got = lib.aaclip_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                               "(make -C aa-clip-iqm_amd/csrc)")
         _lib = lib
     return _lib
 

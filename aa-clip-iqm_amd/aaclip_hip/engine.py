@@ -1,7 +1,10 @@
 """Host-side executor: turns torch tensors into raw HIP pointers and sequences
-the C-ABI calls of libaaclip_hip.so.  PyTorch is only used for device memory,
-the current stream and parameter containers; no torch op computes anything on
-the hot path.
+the C-ABI calls of libaaclip_hip.so.  PyTorch is used for device memory, the
+current stream and parameter containers; every per-token computation is a kernel
+of the library.  The torch ops that do compute are load-time weight preparation
+(WeightCache: dtype conversion / transposes; FoldCache: W*gamma, its row sums and
+b + W@beta, once per parameter version) -- and, outside this module, the <=16-row
+anchor mean and the [B,768].[768] image score in forward_utils.py.
 
 Layout: the residual stream is batch-first, fp32, [B*L, D] contiguous for the
 whole tower (the reference permutes to LND, model/adapter.py:158; token rows are

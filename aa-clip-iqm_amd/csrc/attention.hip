@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   }
 }
 
+#ifdef AACLIP_MEASURE   // software-pipelined variant: measured slower, kept for A/B runs (measurement library)
 // ---------------------------------------------------------------------------
 // Software-pipelined variant (32 query rows per wave, 4-stage K/V ring): the
 // S^T MFMA chain of key tile j+1 is issued BEFORE the exponentials of tile j and
@@ -737,6 +738,8 @@ __global__ __launch_bounds__(256, 2) void attn16p_kernel(const T* __restrict__ q
   }
 }
 
+#endif  // AACLIP_MEASURE
+
 // ------------------------------------------------------------------ fp32 path
 __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L,
                                                      int H, int causal) {
@@ -833,13 +836,22 @@ __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ q
 }
 
 static int g_attn_variant = 0;  // 1 = always the 2-stage 128-row kernel (A/B measurements)
-void set_attn_variant(int v) { g_attn_variant = v; }
+bool set_attn_variant(int v) {
+#ifdef AACLIP_MEASURE
+  const bool ok = v >= 0 && v <= 2;
+#else
+  const bool ok = v == 0 || v == 1;
+#endif
+  if (ok) g_attn_variant = v;
+  return ok;
+}
 
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
                       hipStream_t s) {
   if (dtype == AACLIP_F32) {
     dim3 g((L + 255) / 256, H, B);
     hipLaunchKernelGGL(attn32_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
+#ifdef AACLIP_MEASURE
   } else if (L >= 512 && g_attn_variant == 2) {   // software-pipelined kernel
     dim3 g((L + 127) / 128, H, B);
     if (dtype == AACLIP_F16) {
@@ -849,6 +861,7 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
       if (log2q) hipLaunchKernelGGL((attn16p_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
       else hipLaunchKernelGGL((attn16p_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
     }
+#endif
   } else if (L >= 512 && g_attn_variant != 1) {
     dim3 g((L + 255) / 256, H, B);
     if (dtype == AACLIP_F16) {

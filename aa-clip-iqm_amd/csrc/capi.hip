@@ -22,6 +22,11 @@ static int fail(int code, const char* msg) {
   } while (0)
 
 static int finish(const char* what) {
+  if (const char* le = take_launch_error()) {   // a launcher was asked for a kernel it does not have: nothing ran for it
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, le);
+    (void)hipGetLastError();
+    return -4;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -94,20 +99,44 @@ int aaclip_profile_end(float* ms, int* tags, int max_n) {
 }
 
 int aaclip_set_gemm_variant(int v) {
-  set_gemm_variant(v & 0xFF);
-  set_attn_variant((v >> 8) & 0xFF);   // bits 8..15: attention kernel selection
+  REQUIRE(v >= 0 && (v >> 18) == 0, "set_gemm_variant: unknown bits");
+  // Validate everything before changing anything: a rejected call leaves the selection as it was.
+  const int gv = v & 0xFF, av = (v >> 8) & 0xFF;
+#ifdef AACLIP_MEASURE
+  REQUIRE((gv <= 60 || gv == 70) && av <= 2, "set_gemm_variant: no such kernel variant");
+#else
+  REQUIRE(gv <= 1 && av <= 1,
+          "set_gemm_variant: libaaclip_hip.so only has GEMM variants 0/1 and attention variants 0/1; A/B variants, "
+          "timing ablations (wrong results) and stamp builds live in libaaclip_hip_measure.so (make measure)");
+#endif
+  set_gemm_variant(gv);
+  set_attn_variant(av);   // bits 8..15: attention kernel selection
   g_ln_fold = ((v >> 17) & 1) ? 0 : 1;
   set_tail_peel((v >> 16) & 1);  // bit 16: peel the partial last round to the 128-tile kernel (measured: -1.6 %, off by default)
   return 0;
 }
 
 int aaclip_debug_gemm_stamps(double* out3, int nwaves) {
+#ifdef AACLIP_MEASURE
+  REQUIRE(out3, "debug_gemm_stamps: null pointer");
   if (nwaves < 0) {   // persistent kernel: 8 values (cycles per tile of 7 segments, tile count)
     read_gemm_zstamps(out3);
     return 0;
   }
   read_gemm_stamps(out3, nwaves);
   return 0;
+#else
+  (void)out3; (void)nwaves;
+  return fail(-1, "debug_gemm_stamps: stamp kernels are part of libaaclip_hip_measure.so only (make measure)");
+#endif
+}
+
+int aaclip_is_measurement_build(void) {
+#ifdef AACLIP_MEASURE
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int aaclip_version(void) { return AACLIP_ABI_VERSION; }
@@ -330,7 +359,14 @@ int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float m
 
 int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L,
                      int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream) {
-  REQUIRE(x_in, "block: null pointer");
+  REQUIRE(x_in && w, "block: null pointer");
+  REQUIRE(n_blocks >= 1, "block: n_blocks must be positive");
+  // a caller built against another header revision (no size field, fewer pointer fields) is refused here, before
+  // anything reads its struct as if it were ours
+  for (int i = 0; i < n_blocks; ++i)
+    REQUIRE(w[i].struct_bytes == sizeof(aaclip_block_weights),
+            "block: aaclip_block_weights.struct_bytes does not match this library (binding generated from another "
+            "include/aaclip.h revision?)");
   REQUIRE(dtype_ok(dtype), "block: bad dtype");
   REQUIRE(attn_mode >= AACLIP_ATTN_FULL && attn_mode <= AACLIP_ATTN_VV_BATCH, "block: attn_mode must be 0, 1 or 2");
   REQUIRE(attn_mode != AACLIP_ATTN_VV_BATCH || F >= 4 * D, "block: V-V attention needs F >= 4*D workspace columns");

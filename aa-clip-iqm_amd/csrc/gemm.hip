@@ -249,37 +249,64 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
 
 static int g_tail_peel = 0;  // measured: not a win (the 128-tile kernel is too slow for the peeled rows)
 void set_tail_peel(int v) { g_tail_peel = v; }
-static int g_gemm_variant = 0;  // 0 auto, 1 force the 128-tile kernel, 2 force the 256-tile kernel where legal
-void set_gemm_variant(int v) { g_gemm_variant = v; }
+static int g_gemm_variant = 0;  // 0 automatic, 1 force the 128-tile kernel; more in the measurement library only
+
+static thread_local const char* g_launch_err = nullptr;
+void set_launch_error(const char* msg) { if (!g_launch_err) g_launch_err = msg; }
+const char* take_launch_error() { const char* m = g_launch_err; g_launch_err = nullptr; return m; }
+
+bool gemm256_applicable(int dtype, const GemmParams& p) {
+  return dtype != AACLIP_F32 && p.N % 256 == 0 && p.K % 64 == 0 && p.ldc % 8 == 0 && (p.scale_cols % 4) == 0 &&
+         (long)256 * p.lda < (1L << 30) && (long)256 * p.K < (1L << 30);
+}
+
+bool set_gemm_variant(int v) {
+#ifdef AACLIP_MEASURE
+  // 2..5 = 256-tile kernels on 32x32x16 MFMAs (gemm256.hip), 6..60 = the 16x16x32 family incl. timing ablations and
+  // the stamp build (gemm256t.hip), 70 = persistent tiles (gemm256z.hip)
+  const bool ok = v >= 0 && (v <= 60 || v == 70);
+#else
+  const bool ok = v == 0 || v == 1;
+#endif
+  if (ok) g_gemm_variant = v;
+  return ok;
+}
 
 static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+#ifdef AACLIP_MEASURE
   if (g_gemm_variant == 70) {   // persistent tiles (gemm256z.hip); falls through when K/64 is odd or < 4
     if (launch_gemm256z(dtype, epi, p, s)) return;
     launch_gemm256t(dtype, epi, p, s, 14);
     return;
   }
-  if (g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60)) {
+  if (g_gemm_variant >= 6 && g_gemm_variant <= 60) {
     // 16x16x32 MFMA shape; 6 plain, 7 overlapped LDS reads, 8/9/10 staggered with 0/1/2 DMA issues in the load
     // segment, 11..17 timing ablations / stamps of 10 (fp32-out epilogue only), 18 staggered + in-cluster reads,
-    // 19 (default) = 10 with buffer_load ... lds
-    launch_gemm256t(dtype, epi, p, s, g_gemm_variant == 0 ? 14 : g_gemm_variant - 6);
+    // 19 = 10 with buffer_load ... lds, 20 = the default
+    launch_gemm256t(dtype, epi, p, s, g_gemm_variant - 6);
     return;
   }
-  // 32x32x16 kernels: 2 DMA at the phase start, 3 DMA between the MFMAs, 4/5 timing ablations
-  launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : (g_gemm_variant >= 3 ? g_gemm_variant - 2 : 1));
+  if (g_gemm_variant >= 2) {
+    // 32x32x16 kernels: 2 DMA at the phase start, 3 DMA between the MFMAs, 4/5 timing ablations
+    launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : g_gemm_variant - 2);
+    return;
+  }
+#endif
+  launch_gemm256t(dtype, epi, p, s, 14);
 }
 
 // True when launch_gemm will run one of the 16x16x32 256-tile kernels (gemm256t.hip) on the whole problem:
 // those are the kernels whose epilogue implements the LayerNorm-folding options of GemmParams.
 bool gemm_routes_to_256t(int dtype, const GemmParams& p) {
   if (dtype == AACLIP_F32 || !gemm256_applicable(dtype, p) || p.M < 4096) return false;
-  if (!(g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60))) return false;
+  if (!(g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60))) return false;   // > 1: measurement library
   if (g_tail_peel) return false;
   return true;
 }
 
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
-  // variants: 0 auto, 1 128-tile kernel, 2 256-tile kernel, 3 256-tile software-pipelined kernel
+  // variants: 0 automatic (256-tile kernels from M = 4096 rows), 1 the 128-tile kernel, >= 2 (measurement library) 256-tile
+  // kernels at any M
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {
     // Tail peeling: 256x256 tiles run one per CU in rounds of 256.  When the last round would be
     // less than 60 % full, the rows of that partial round go to the 128-tile kernel instead (two

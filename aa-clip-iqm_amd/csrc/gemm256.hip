@@ -22,6 +22,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef AACLIP_MEASURE
+#error "gemm256.hip holds A/B variants and timing ablations: it is part of the measurement library only (make measure)"
+#endif
+
 namespace aaclip {
 
 template <typename T, int EPI>
@@ -408,8 +412,14 @@ static void launch256_t(int epi, const GemmParams& p, hipStream_t s, int pipelin
   const int total = patches_n * patches_m;
   const int grid = ((total + 7) / 8) * 8 * 8 * PN;
   dim3 g(grid), b(512);
-  if (pipelined == 2 && epi == EPI_ACT_F32) { hipLaunchKernelGGL((gemm16_256s_kernel<T, EPI_ACT_F32, 1>), g, b, 0, s, p, PN, patches_n, total); return; }
-  if (pipelined == 3 && epi == EPI_ACT_F32) { hipLaunchKernelGGL((gemm16_256s_kernel<T, EPI_ACT_F32, 2>), g, b, 0, s, p, PN, patches_n, total); return; }
+  if (pipelined == 2 || pipelined == 3) {
+    // timing ablations (wrong results) exist for the fp32-output epilogue only: no silent substitute for the others,
+    // and never an fp32-storing kernel on a 16-bit output buffer
+    if (epi != EPI_ACT_F32) { set_launch_error("gemm: ablation kernels exist for the fp32-output epilogue only"); return; }
+    if (pipelined == 2) hipLaunchKernelGGL((gemm16_256s_kernel<T, EPI_ACT_F32, 1>), g, b, 0, s, p, PN, patches_n, total);
+    else hipLaunchKernelGGL((gemm16_256s_kernel<T, EPI_ACT_F32, 2>), g, b, 0, s, p, PN, patches_n, total);
+    return;
+  }
   if (pipelined) {
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm16_256s_kernel<T, EPI_BIAS, 0>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -427,11 +437,6 @@ static void launch256_t(int epi, const GemmParams& p, hipStream_t s, int pipelin
     case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256_kernel<T, EPI_ACT_F32>), g, b, 0, s, p, PN, patches_n, total); break;
     case EPI_PATCH: hipLaunchKernelGGL((gemm16_256_kernel<T, EPI_PATCH>), g, b, 0, s, p, PN, patches_n, total); break;
   }
-}
-
-bool gemm256_applicable(int dtype, const GemmParams& p) {
-  return dtype != AACLIP_F32 && p.N % 256 == 0 && p.K % 64 == 0 && p.ldc % 8 == 0 && (p.scale_cols % 4) == 0 &&
-         (long)256 * p.lda < (1L << 30) && (long)256 * p.K < (1L << 30);
 }
 
 void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined) {

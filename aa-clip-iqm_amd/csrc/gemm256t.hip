@@ -192,6 +192,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
   }
 }
 
+#ifdef AACLIP_MEASURE   // lock-step predecessors of the staggered kernels, kept for A/B runs (measurement library)
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm16_256t_kernel(GemmParams p, int PN, int patches_n, int total_patches) {
   typedef typename Elem<T>::vec8 vec8;
@@ -496,6 +497,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_256u_kernel(GemmParams p, int P
   epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane);
 }
 
+#endif  // AACLIP_MEASURE
+
 // ---------------------------------------------------------------------------
 // Staggered variant.  Every phase is split into a LOAD segment (counted DMA wait,
 // LDS fragment reads, optionally one DMA issue) and a COMPUTE segment (16 MFMAs with
@@ -511,7 +514,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_256u_kernel(GemmParams p, int P
 // the LOAD segment (the rest go between the MFMAs).
 // Diagnostic stamps (ABL == 7 build only): per wave, cycles summed over the K loop for
 // [0] load segment + its barrier wait, [1] compute segment, [2] barrier wait after compute.
+#ifdef AACLIP_MEASURE
 __device__ unsigned long long g_stamp[6 * 16384];
+#else
+__device__ unsigned long long g_stamp[6];   // never written: the stamp build (ABL == 7) is not instantiated in the product library
+#endif
 AACLIP_DEV unsigned long long stamp() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
@@ -737,6 +744,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256v_kernel(GemmParams p, int P
 }
 
 // ---------------------------------------------------------------------------
+#ifdef AACLIP_MEASURE
 // Staggered + overlapped: the LOAD segment only waits for DMA and issues the two
 // DMA instructions of the phase; the LDS fragment reads of the next quadrant ride
 // inside the MFMA cluster (in-place, as in gemm16_256u_kernel).  With waves 4-7 one
@@ -912,6 +920,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_256w_kernel(GemmParams p, int P
 }
 
 // ---------------------------------------------------------------------------
+#endif  // AACLIP_MEASURE
+
 // Staggered kernel with two N-side fragment sets (the default).  Tried on top of it and dropped
 // (no gain): a persistent workgroup walking the tile list (static order and per-XCD
 // atomic queues with stealing), start-time de-phasing of the first round, smaller XCD patches.  B0 stays in registers for the
@@ -1107,9 +1117,10 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
   const int total = patches_n * patches_m;
   const int grid = ((total + 7) / 8) * 8 * 8 * PN;
   dim3 g(grid), b(512);
+  if (epi < EPI_BIAS || epi > EPI_PATCH) { set_launch_error("gemm: no 256-tile kernel for this epilogue"); return; }
   if (overlapped >= 14 && ((p.K >> 6) & 1)) overlapped = 13;   // the two-set kernels need an even K-tile count
   if (overlapped == 14 || (overlapped >= 30 && overlapped < 40)) {   // staggered, two N-side fragment sets
-    // 14: 8-row patches, no start stagger.  30 + 8*b + k: balanced patches if b, k start slots
+    // 14: 8-row patches, no start stagger.  30 + 8*b + k (measurement runs): balanced patches if b, k start slots
     int PMx = 8, stg = 1;
     if (overlapped >= 30) {
       const int code = overlapped - 30;
@@ -1140,6 +1151,7 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
     }
     return;
   }
+#ifdef AACLIP_MEASURE
   if (overlapped == 12) {   // staggered + overlapped LDS reads
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm16_256w_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -1150,11 +1162,11 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
     }
     return;
   }
-  if (overlapped == 40 && epi == EPI_ACT_F32) {   // timing ablation: staggered kernel without epilogue stores
-    hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 8>), g, b, 0, s, p, PN, patches_n, total);
-    return;
-  }
-  if (overlapped >= 5 && overlapped <= 11 && epi == EPI_ACT_F32) {   // timing ablations of the staggered kernel (GL = 2)
+  if (overlapped == 40 || (overlapped >= 5 && overlapped <= 11)) {
+    // Timing ablations and the stamp build of the staggered kernel (GL = 2).  They exist for the fp32-output epilogue
+    // only (their stores, where they store at all, are 4 bytes per element): any other epilogue has no such kernel and
+    // is an error -- launching one on a 16-bit output buffer overruns it by a factor of two.
+    if (epi != EPI_ACT_F32) { set_launch_error("gemm: ablation/stamp kernels exist for the fp32-output epilogue only"); return; }
     switch (overlapped) {
       case 5: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 1>), g, b, 0, s, p, PN, patches_n, total); break;
       case 6: hipLaunchKernelGGL((gemm16_256v_kernel<T, EPI_ACT_F32, 2, 2>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -1167,8 +1179,7 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
     }
     return;
   }
-  if (overlapped >= 5 && overlapped <= 11) overlapped = 4;
-  if (overlapped >= 2) {   // staggered kernel, GL = overlapped - 2 DMA instructions in the load segment
+  if (overlapped >= 2 && overlapped <= 4) {   // staggered kernel, GL = overlapped - 2 DMA instructions in the load segment
 #define LV(E) { if (overlapped == 2) hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 0>), g, b, 0, s, p, PN, patches_n, total); \
                else if (overlapped == 3) hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 1>), g, b, 0, s, p, PN, patches_n, total); \
                else hipLaunchKernelGGL((gemm16_256v_kernel<T, E, 2>), g, b, 0, s, p, PN, patches_n, total); }
@@ -1182,7 +1193,7 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
 #undef LV
     return;
   }
-  if (overlapped) {
+  if (overlapped == 1) {
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
       case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256u_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
@@ -1192,15 +1203,21 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
     }
     return;
   }
-  switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_RESID>), g, b, 0, s, p, PN, patches_n, total); break;
-    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_ACT_F32>), g, b, 0, s, p, PN, patches_n, total); break;
-    case EPI_PATCH: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_PATCH>), g, b, 0, s, p, PN, patches_n, total); break;
+  if (overlapped == 0) {
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_GELU>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_BIAS_RESID>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_ACT_F32>), g, b, 0, s, p, PN, patches_n, total); break;
+      case EPI_PATCH: hipLaunchKernelGGL((gemm16_256t_kernel<T, EPI_PATCH>), g, b, 0, s, p, PN, patches_n, total); break;
+    }
+    return;
   }
+#endif  // AACLIP_MEASURE
+  set_launch_error("gemm: unknown 256-tile kernel id");
 }
 
+#ifdef AACLIP_MEASURE
 void read_gemm_stamps(double* out6, int nwaves) {
   static unsigned long long host[6 * 16384];
   (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(host));
@@ -1214,6 +1231,8 @@ void read_gemm_stamps(double* out6, int nwaves) {
   }
   for (int j = 0; j < 6; ++j) out6[j] = n ? sum[j] / n : 0;
 }
+
+#endif  // AACLIP_MEASURE
 
 void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped) {
   if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped);

@@ -19,6 +19,10 @@
 #include "kernels.h"
 #include "mma16.h"
 
+#ifndef AACLIP_MEASURE
+#error "gemm256z.hip (persistent-tile experiment, stamp builds) is part of the measurement library only (make measure)"
+#endif
+
 namespace aaclip {
 
 // vm operations (global stores) the epilogue issues per wave for a full tile

@@ -33,14 +33,27 @@ struct GemmParams {
 const char* gemm_check(int dtype, int epi, const GemmParams& p);
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s);
 bool gemm256_applicable(int dtype, const GemmParams& p);
+// 256-tile kernels on 16x16x32 MFMAs.  kernel_id: 14 = the default two-fragment-set kernel (falls back to 13 when
+// K/64 is odd), 13 = its one-set predecessor; every other id exists only in the measurement library.  A (kernel_id,
+// epilogue) pair without a kernel launches NOTHING and records a launch error (launch_error()).
+void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int kernel_id);
+// Kernel selection for A/B runs.  The product library knows GEMM variants 0 (automatic) and 1 (128-tile kernel) and
+// attention variants 0 and 1 (128-query kernel); both return false for anything else and leave the selection alone.
+bool set_gemm_variant(int v);
+bool set_attn_variant(int v);
+void set_tail_peel(int v);
+// Sticky per-thread launch error: set by a launcher that was asked for a kernel it does not have; capi's finish()
+// reports and clears it, so the entry point returns rc < 0 instead of running something else.
+void set_launch_error(const char* msg);
+const char* take_launch_error();
+#ifdef AACLIP_MEASURE
+// Measurement library only (libaaclip_hip_measure.so, `make measure`): A/B variants, timing ablations that compute
+// WRONG results, and s_memtime stamp builds.  None of this is compiled into libaaclip_hip.so.
 void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int pipelined);
-void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped);
 void read_gemm_zstamps(double* out8);   // -DZ_STAMP builds only, zeros otherwise
 bool launch_gemm256z(int dtype, int epi, const GemmParams& p, hipStream_t s);   // persistent tiles; false = not applicable
-void set_gemm_variant(int v);
-void set_tail_peel(int v);
 void read_gemm_stamps(double* out3, int nwaves);
-void set_attn_variant(int v);
+#endif
 
 // fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]
 // log2q != 0: q is pre-multiplied by log2(e) as well (16-bit kernels only)

@@ -100,8 +100,10 @@ def metrics_eval(pixel_label, image_label, pixel_preds, image_preds, class_names
     import numpy as np
     from sklearn.metrics import average_precision_score, roc_auc_score
 
-    pixel_preds = np.asarray(pixel_preds, dtype=np.float64)
-    image_preds = np.asarray(image_preds, dtype=np.float64)
+    # arithmetic stays in the callers' dtype (float32 arrays in test_last.py), as in the reference: the min-max
+    # normalisation decides which pixels tie, and ties decide AUROC / AP digits
+    pixel_preds = np.asarray(pixel_preds)
+    image_preds = np.asarray(image_preds)
     pixel_label = np.asarray(pixel_label)
     image_label = np.asarray(image_label)
     if pixel_preds.max() != 1:
@@ -110,6 +112,10 @@ def metrics_eval(pixel_label, image_label, pixel_preds, image_preds, class_names
         image_preds = (image_preds - image_preds.min()) / (image_preds.max() - image_preds.min())
     if pixel_preds.ndim == 4 and pixel_preds.shape[1] == 1:
         pixel_preds = pixel_preds[:, 0]
+    elif pixel_preds.ndim == 2:                      # [N, pixels] -> [N, side, side] (:261-267)
+        side = int(pixel_preds.shape[1] ** 0.5)
+        if side * side == pixel_preds.shape[1]:
+            pixel_preds = pixel_preds.reshape(pixel_preds.shape[0], side, side)
     if image_preds.ndim == 2 and image_preds.shape[1] == 2:
         image_preds = image_preds[:, 0]
     elif image_preds.ndim > 1:

@@ -30,15 +30,18 @@
 extern "C" {
 #endif
 
-#define AACLIP_ABI_VERSION 2
+#define AACLIP_ABI_VERSION 3
 
 enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2 };
 enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1 };
 /* generic GEMM epilogues (aaclip_gemm) */
 enum { AACLIP_EPI_BIAS = 0, AACLIP_EPI_BIAS_GELU = 1, AACLIP_EPI_BIAS_RESID = 2, AACLIP_EPI_ACT_F32 = 3 };
 
-int aaclip_version(void);
+int aaclip_version(void);            /* AACLIP_ABI_VERSION the library was built from; bind only if it matches */
 const char* aaclip_last_error(void);
+/* 0 for libaaclip_hip.so.  1 for libaaclip_hip_measure.so, the separate build (`make measure`) that adds A/B kernel
+ * variants, timing ablations that compute WRONG results and s_memtime stamp kernels: never bind a product to it. */
+int aaclip_is_measurement_build(void);
 
 /* Scratch needed by any call below for `rows` token rows of width D, MLP width F,
  * embed width E (pass the largest you will use). */
@@ -47,6 +50,11 @@ size_t aaclip_workspace_bytes(int dtype, long rows, int D, int F, int E);
 /* Weights of one ResidualAttentionBlock (reference model/transformer.py:183-258)
  * plus the optional residual adapter applied after it (model/adapter.py:163-170). */
 typedef struct aaclip_block_weights {
+  /* ABI version >= 3: sizeof(aaclip_block_weights) as the CALLER compiled it.  Every entry point that takes this
+   * struct rejects (rc < 0, nothing launched) an element whose struct_bytes differs from the library's own sizeof, so
+   * a binding generated from an older header (13 or 19 pointer fields, no size field: its first word is the ln1_w
+   * pointer) is refused instead of being read past its end. */
+  size_t struct_bytes;
   const float* ln1_w;   /* [D] */
   const float* ln1_b;
   const void* qkv_w;    /* attn.in_proj_weight [3D, D], dtype */
@@ -181,17 +189,20 @@ int aaclip_profile_begin(unsigned tag_mask, int capacity);
 int aaclip_profile_end(float* ms, int* tags, int max_n);
 
 /* Kernel selection for A/B measurements (tools/bench_gemm.py, tools/bench_attn.py); 0 = automatic (default).
- * bits 0..7   GEMM: 1 = always the 128x128-tile kernel; 2..5 = 256-tile kernels on 32x32x16 MFMAs; 6..60 = the
- *             16x16x32 family (20 = the default kernel, others: lock-step / in-cluster-read variants, timing
- *             ablations and the stamp build); 70 = persistent tiles (gemm256z.hip)
- * bits 8..15  attention: 1 = always the 128-query kernel, 2 = software-pipelined kernel
+ * bits 0..7   GEMM: 1 = always the 128x128-tile kernel.  Measurement library only: 2..5 = 256-tile kernels on
+ *             32x32x16 MFMAs; 6..60 = the 16x16x32 family (20 = the default kernel, others: lock-step /
+ *             in-cluster-read variants, timing ablations and the stamp build); 70 = persistent tiles (gemm256z.hip)
+ * bits 8..15  attention: 1 = always the 128-query kernel; measurement library only: 2 = software-pipelined kernel
  * bit 16      peel the partial last round of 256-tile GEMMs to the 128-tile kernel (off by default: -1.6 %)
- * bit 17      turn the LayerNorm folding of aaclip_block(s) off */
+ * bit 17      turn the LayerNorm folding of aaclip_block(s) off
+ * Every selectable kernel of libaaclip_hip.so computes the same function.  A value that names a variant the loaded
+ * library does not contain is rejected (rc < 0) and leaves the selection unchanged; inside the measurement library a
+ * (variant, epilogue) pair without a kernel makes the affected call return rc < 0 instead of running a substitute. */
 int aaclip_set_gemm_variant(int v);
 
 /* Diagnostics of stamp builds (tools/gemm_stamps.py, tools/gemm_zstamps.py): nwaves >= 0 -> 6 averaged s_memtime
  * segment sums of GEMM variant 17; nwaves < 0 -> 8 values of the persistent kernel built with -DZ_STAMP (zeros in
- * a normal build).  `out` is HOST memory. */
+ * a normal build).  `out` is HOST memory.  rc < 0 in libaaclip_hip.so (measurement library only). */
 int aaclip_debug_gemm_stamps(double* out, int nwaves);
 
 /* Building blocks, exported for unit parity tests and for callers that fuse differently. */

@@ -13,15 +13,112 @@ from aaclip_hip import _lib, engine, synth
 from conftest import GOLDEN, REPO
 
 
+def _header_abi_version():
+    header = open(os.path.join(REPO, "include", "aaclip.h")).read()
+    return int(re.search(r"#define\s+AACLIP_ABI_VERSION\s+(\d+)", header).group(1))
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
-    assert lib.aaclip_version() == 2
+    assert lib.aaclip_version() == _header_abi_version() == _lib.ABI_VERSION
+    assert lib.aaclip_is_measurement_build() == 0      # the product library carries no ablation / stamp kernels
     header = open(os.path.join(REPO, "include", "aaclip.h")).read()
     declared = set(re.findall(r"\b(aaclip_[a-z_0-9]+)\s*\(", header))
     declared.discard("aaclip_block_weights")
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: make + load + ABI version from the header (it once asserted a stale constant)."""
+    import __graft_entry__ as G
+    G.build()
+
+
+def test_block_weights_struct_matches_header():
+    header = open(os.path.join(REPO, "include", "aaclip.h")).read()
+    body = re.search(r"typedef struct aaclip_block_weights \{(.*?)\} aaclip_block_weights;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(\w+)\s*;", body)
+    assert fields == [n for n, _ in _lib.BlockWeights._fields_]
+    assert _lib.BlockWeights().struct_bytes == ctypes.sizeof(_lib.BlockWeights) == 8 * len(fields)
+
+
+def test_short_or_old_block_struct_is_rejected():
+    """A binding generated from an older header (13 pointer fields: ABI 1; 19: ABI 2; neither has the size field)
+    must get rc < 0 from every entry point that takes the struct -- before anything is read past its end or
+    launched.  Runs without a GPU: the check precedes every HIP call."""
+    lib = _lib.load()
+
+    class Old13(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in (
+            "ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc_w", "fc_b", "proj_w",
+            "proj_b", "adapter_w")]
+
+    class Old19(ctypes.Structure):
+        _fields_ = Old13._fields_ + [(n, ctypes.c_void_p) for n in (
+            "fc_w_fold", "fc_fold_s", "fc_fold_b", "qkv_w_fold", "qkv_fold_s", "qkv_fold_b")]
+
+    block = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, *([ctypes.c_int] * 7),
+                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)(("aaclip_block", lib))
+    blocks_to = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                 ctypes.c_float, *([ctypes.c_int] * 7), ctypes.c_void_p, ctypes.c_size_t,
+                                 ctypes.c_void_p)(("aaclip_blocks_to", lib))
+    for Old in (Old13, Old19):
+        w = Old()
+        for n, _ in Old._fields_:
+            setattr(w, n, 0x7f0000001000)      # plausible device addresses: nothing here may be dereferenced
+        rc = block(0x7f0000002000, ctypes.addressof(w), 0.1, 4, 1370, 1024, 16, 4096, 0, _lib.F16, 0x7f0000003000,
+                   1 << 40, None)
+        assert rc < 0 and b"struct_bytes" in lib.aaclip_last_error()
+        rc = blocks_to(0x7f0000002000, 0x7f0000004000, ctypes.addressof(w), 1, 0.1, 4, 1370, 1024, 16, 4096, 0,
+                       _lib.F16, 0x7f0000003000, 1 << 40, None)
+        assert rc < 0 and b"struct_bytes" in lib.aaclip_last_error()
+    # a current struct with a tampered size is refused too; the right size passes this check (and then fails the
+    # next one, a null weight pointer, still without touching the GPU)
+    w = _lib.BlockWeights()
+    w.struct_bytes = 13 * 8
+    rc = lib.aaclip_block(0x7f0000002000, ctypes.byref(w), 0.1, 4, 1370, 1024, 16, 4096, 0, _lib.F16, 0x7f0000003000,
+                          1 << 40, None)
+    assert rc < 0 and b"struct_bytes" in lib.aaclip_last_error()
+
+
+def test_product_library_refuses_measurement_variants():
+    """Timing ablations (wrong results), A/B variants and stamp kernels are not in libaaclip_hip.so: selecting one is
+    an error and leaves the selection unchanged; no environment variable selects kernels any more."""
+    lib = _lib.load()
+    for v in (2, 5, 11, 17, 20, 46, 70, 2 << 8, 1 << 18, -1):
+        assert lib.aaclip_set_gemm_variant(v) < 0, v
+    assert b"measure" in lib.aaclip_last_error() or b"unknown" in lib.aaclip_last_error()
+    for v in (1, 1 << 8, 1 << 16, 1 << 17, 0):
+        assert lib.aaclip_set_gemm_variant(v) == 0, v
+    assert lib.aaclip_debug_gemm_stamps(None, 4) < 0
+    src = open(os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "_lib.py")).read()
+    assert "AACLIP_GEMM_VARIANT" not in src
+
+
+def test_measurement_library_has_no_substitute_kernels():
+    """Regression for the round-1 GPU fault: an fp32-storing timing ablation was launched for a
+    product whose output buffer is 16-bit and overran it.  The ablations now live in libaaclip_hip_measure.so only,
+    exist for the fp32-output epilogue only, and any other (variant, epilogue) pair returns rc < 0 WITHOUT launching
+    (so this runs on a CPU box with made-up pointers)."""
+    if not os.path.exists(_lib.MEASURE_LIB_PATH):
+        pytest.skip("measurement library not built (make -C aa-clip-iqm_amd/csrc measure)")
+    m = ctypes.CDLL(_lib.MEASURE_LIB_PATH)
+    m.aaclip_last_error.restype = ctypes.c_char_p
+    res, args = _lib.SIGNATURES["aaclip_gemm"]
+    m.aaclip_gemm.restype, m.aaclip_gemm.argtypes = res, args
+    assert m.aaclip_is_measurement_build() == 1 and m.aaclip_version() == _lib.ABI_VERSION
+    M, N, K = 8192, 1024, 1024
+    for variant in (4, 5, 11, 12, 13, 14, 15, 16, 17, 46):      # 32x32x16 ablations, 16x16x32 ablations + stamp build
+        assert m.aaclip_set_gemm_variant(variant) == 0
+        for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_BIAS_RESID):
+            rc = m.aaclip_gemm(_lib.F16, epi, 0x7f0000001000, K, 0x7f0000002000, 0x7f0000003000, 0x7f0000004000, N,
+                               M, N, K, 0, 0, 1.0, None)
+            assert rc < 0 and b"fp32-output epilogue only" in m.aaclip_last_error(), (variant, epi)
+    assert m.aaclip_set_gemm_variant(61) < 0 and m.aaclip_set_gemm_variant(3 << 8) < 0
+    assert m.aaclip_set_gemm_variant(0) == 0
 
 
 def test_workspace_bytes_monotone():

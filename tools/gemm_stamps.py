@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "aa-clip-iqm_amd"))
 import torch
+os.environ.setdefault("AACLIP_LIB", os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "libaaclip_hip_measure.so"))   # A/B variants live in the measurement library (make measure)
 from aaclip_hip import _lib
 lib = _lib.load()
 lib.aaclip_debug_gemm_stamps.restype = C.c_int
