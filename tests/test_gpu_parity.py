@@ -350,8 +350,10 @@ def test_full_model_vs_reference_golden(dev, golden_full, full_weights, code):
     ganch = T(golden_full["full.anchors_bottle"]).to(dev)
     for i in range(4):
         raw = engine.anomaly_map([seg[i]], ganch, 37, 1, 1.0)   # S == grid: identity upsample
-        assert_close(raw, T(golden_full[f"full.map_pre_blur{i}"]), 10 * atol if code != F32 else 5e-3, rtol,
-                     f"pre-blur map {i}")
+        # measured on MI355X (tests/test_gpu_configs.py docstring, profiles/r02_parity_errors.json): fp32 path max
+        # |err| ~1e-5; fp16 path <= 2.9e-3 per level -- the fp16 tower's rounding noise x50, not the head
+        assert_close(raw, T(golden_full[f"full.map_pre_blur{i}"]), 4e-3 if code != F32 else 1e-4,
+                     rtol if code != F32 else 1e-3, f"pre-blur map {i}")
     tfb = ganch.unsqueeze(0).repeat(2, 1, 1)
     sampled_close(golden_full, "full.map_train3", FU.calculate_similarity_map(seg[3], tfb, 518, test=False),
                   2e-3 if code != F32 else 2e-4, rtol)
@@ -447,7 +449,12 @@ def test_auroc_parity_on_synthetic_masks(dev, full_weights):
     oanch = O.class_anchor(otxt[0:1], otxt[1:2])
     omap = O.anomaly_map(oseg, oanch, 518, "Industrial")
     oscore = O.image_score(odet, oanch)
-    assert_close(amap, omap, 2e-2, 1e-2, "anomaly map (x100 cosines, fp16 towers on both sides of the dot)")
+    # 4-level sum of x50 cosine differences from two fp16 towers (visual AND text anchors come from the fp16 path
+    # here, the oracle's from fp32): measured max |err| recorded by tests/test_gpu_configs.py; north star x 6
+    err = (amap.double() - omap.double()).abs()
+    print(f"fused anomaly map vs oracle: max |err| {err.max().item():.3e}, rms {err.pow(2).mean().sqrt().item():.3e}, "
+          f"max share of 1e-3+1e-2|ref| {(err / (1e-3 + 1e-2 * omap.double().abs())).max().item():.2f}")
+    assert_close(amap, omap, 6e-3, 1e-2, "anomaly map (x100 cosines, fp16 towers on both sides of the dot)")
     a = roc_auc_score(masks.reshape(-1), amap.numpy().reshape(-1))
     b = roc_auc_score(masks.reshape(-1), omap.numpy().reshape(-1))
     assert abs(a - b) <= 1e-3, (a, b)
