@@ -89,6 +89,19 @@ def load() -> C.CDLL:
     return _lib
 
 
+def kernel_source_revision(files=("gemm256t.hip", "gemm.hip", "common.h", "mma16.h", "kernels.h")) -> str:
+    """sha256 (first 16 hex digits) over the sources of the large-batch GEMM kernels, in the order given.  Offline
+    counter measurements committed under profiles/ record it, and bench.py only reports a measurement taken on the
+    sources it is running (a stale file yields traffic: null)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(os.path.dirname(_HERE), "csrc")
+    for name in files:
+        with open(os.path.join(src, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().aaclip_last_error()

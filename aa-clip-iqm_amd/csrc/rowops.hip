@@ -331,12 +331,13 @@ __global__ void det_finish_kernel(const float* __restrict__ part, float* __restr
     dst[(long)b * E + i] = a * inv_n;
   }
 }
-// scratch holds B * slices * E floats; the slice count adapts to scratch_floats
+// scratch holds B * slices * E floats.  The slice count must NOT depend on B: the order in which an image's patches
+// are added has to be the same in every batch, or an image's det token changes in the last bit with the batch it
+// happens to share (found by the B = 128 case of tests/test_gpu_configs.py: 2048 / B slices gave 16 instead of 32).
 void launch_det_mean(const float* src, float* scratch, size_t scratch_floats, float* dst, int B, int L, int skip, int E,
                      hipStream_t s) {
   const int n = L - skip;
-  int slices = 2048 / B;
-  slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+  int slices = 32;
   if (slices > n) slices = n;
   const size_t fit = scratch_floats / ((size_t)B * E);
   if ((size_t)slices > fit) slices = fit < 1 ? 1 : (int)fit;

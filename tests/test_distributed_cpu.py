@@ -50,3 +50,41 @@ def _worker(rank, world, port, total):
 @pytest.mark.parametrize("total", [8, 7])
 def test_two_rank_gather(total):
     mp.spawn(_worker, args=(2, _free_port(), total), nprocs=2, join=True)
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without torchrun: the process becomes a launcher, starts 2 child ranks before
+    touching any GPU, and rank 0 reports n_gpus = ranks_seen = 2 with one all-gather of 2 x batch rows per step.
+    CPU rehearsal of the control flow (gloo, stand-in step): the real path needs an MI355X."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 16
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["steps"] == 3
+    assert len(d["per_rank_images_per_s"]) == 2 and d["rows_all_gathered_per_step"] == 16
+    assert d["launch"] == "self-launched child ranks"
+    assert d["value"] is None and "REHEARSAL" in d["metric"]      # never mistaken for a measurement
+    # one rank: no launcher, same line shape
+    r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
+                         "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["ranks_seen"] == 1 and d1["launch"] == "single process"
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--precision", "nope", "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0

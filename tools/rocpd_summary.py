@@ -7,8 +7,12 @@
 """
 import csv
 import json
+import os
 import sqlite3
 import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "aa-clip-iqm_amd"))
 
 
 def stats(db_path, out_csv):
@@ -47,8 +51,10 @@ def main():
         f = counter_values(fetch_db, sub)["FETCH_SIZE"]
         w = counter_values(write_db, sub)["WRITE_SIZE"]
         f_kb, w_kb = sum(f) / len(f), sum(w) / len(w)
+        from aaclip_hip._lib import kernel_source_revision
         doc = {
             "kernel": sub, "shape": [M, N, K], "launches": [len(f), len(w)],
+            "kernel_revision": kernel_source_revision(),   # bench.py refuses this file once the kernel sources change
             "FETCH_SIZE_raw_kb": f_kb, "WRITE_SIZE_raw_kb": w_kb,
             "fetch_bytes_corrected_x2": f_kb * 1024 * 2, "write_bytes": w_kb * 1024,
             "traffic_bytes_per_launch": f_kb * 1024 * 2 + w_kb * 1024,
