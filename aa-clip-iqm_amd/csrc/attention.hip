@@ -15,6 +15,8 @@
 // L need not be a multiple of anything: out-of-range keys are masked to -inf,
 // out-of-range query rows are computed on clamped data and not stored.
 // fp32 kernel: plain VALU flash attention, one query per lane (parity path).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -240,21 +242,55 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 // LDS and every DMA'd byte feeds twice the MFMA work, and the two blocks give
 // the scheduler two independent softmax chains.  K/V tiles go through a 4-stage
 // ring (three tiles = 48 KiB in flight per workgroup, two workgroups per CU)
-// with counted vmcnt waits: the 2-stage kernel above was bound by DMA latency x
-// bytes in flight, not by MFMA or VALU.
+// with counted vmcnt waits.
+//
+// At head dim 64 the kernel is bound by VALU ISSUE, not by the matrix pipe: per
+// 64-key tile a wave issues 32 MFMAs (1024 pipe cycles) and needs 64 v_exp_f32
+// (8 issue cycles each).  Round-1 counters (profiles/r02a_attn_pmc.json): 11.7
+// VALU instructions per MFMA, VALU issue busy 58 %, MFMA pipe busy 34 %.  Most of
+// those instructions were not softmax arithmetic, so this version removes them:
+//   * key masking (out-of-range / causal) was if-converted by hipcc into 64
+//     v_cndmask + ~77 v_cmp per tile on EVERY tile: masking is now a real
+//     wave-uniform branch, taken only by the tiles that need it (the last tile
+//     of a row of keys, the diagonal tiles when causal);
+//   * the S^T accumulators were re-initialised to -max with 64 v_mov per tile:
+//     the chains now start from persistent 16-register tuples holding -max
+//     (MFMA reads C from one tuple and writes D to another), rewritten only when
+//     a row maximum grows;
+//   * K/V DMA addresses cost 64-bit VALU arithmetic per instruction: the DMA is a
+//     buffer_load ... lds with a per-lane 32-bit offset fixed for the whole
+//     kernel and the tile advance in the SCALAR offset (no VALU per DMA);
+//   * the cross-half exchanges of row maxima and row sums are v_permlane32_swap
+//     (VALU, inline asm: the clang builtin is broken) instead of ds_bpermute_b32
+//     (an LDS round trip on the critical path);
+//   * the ring is walked with a run-time stage index (6 v_add per tile) instead of
+//     a 4x unrolled body.
+// Workgroups are numbered so that the query blocks of one (image, head) -- which
+// stream the same K/V rows -- run on the same XCD at the same time and share its
+// L2 (before: 2.3 GB fetched per launch for 0.54 GB of q/k/v).
+#ifdef AACLIP_MEASURE
+__device__ unsigned long long g_attn_passes[4];   // measurement library only: tile passes by kind (read_attn_passes)
+#endif
 template <typename T, bool LOG2Q>
 __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
-                                                          int causal) {
+                                                          int causal, int nqt, int total, int per_xcd) {
   typedef typename Elem<T>::vec8 vec8;
   typedef typename Elem<T>::vec4 vec4;
   typedef short i16x8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) char smem[65536];  // 4 stages x (K 8K + V 8K)
   constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float P_LIMIT = 32768.f;   // bound of a lane's 32-key partial row sum on the fast path (f16 max 65504)
+
+  // XCD-aware numbering: workgroup ids are dealt round-robin over the 8 XCDs, so ids with equal id % 8 share an L2;
+  // each XCD walks a contiguous range of (image, head, query block) with the query block fastest
+  const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (lin >= total || (int)(blockIdx.x >> 3) >= per_xcd) return;   // whole workgroup, before any barrier
+  const int qt = lin % nqt, bh = lin / nqt;
+  const int head = bh % H, b = bh / H;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int D = H * 64;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * L * ld + head * 64;
@@ -269,17 +305,40 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
   }
+  // plain aaclip_attention contract (LOG2Q = false): q carries head_dim^-1/2 only.  f16: move it to log2 units HERE,
+  // once per query fragment (one more rounding of q, |d score| <= 2^-11 |score|), so that the tile loop is the same
+  // as on the block path.  bf16 cannot afford a second 8-bit rounding of q: it keeps the per-score multiply
+  // (POSTSCALE: 64 v_fma per tile, plain API only -- the block path is LOG2Q for every 16-bit type).
+  constexpr bool POSTSCALE = !LOG2Q && !std::is_same<T, f16>::value;
+  if (!LOG2Q && !POSTSCALE) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qb][ks][j] = from_float<T>(to_float<T>(qf[qb][ks][j]) * LOG2E);
+  }
 
-  const T* ksrc[2];
-  const T* vsrc[2];
-  int drow[2];
+  // K/V DMA: buffer_load ... lds issued from an asm statement (dma16).  Descriptor base = this (image, head)'s q
+  // column block, built from readfirstlane'd words (provably wave-uniform), per-lane byte offsets fixed for the whole
+  // kernel, tile advance in the scalar offset.  Why asm: hipcc orders every LDS read behind ALL LDS-DMA it knows to
+  // be pending (s_waitcnt vmcnt(0) in front of the V reads of every tile: the ring was drained once per tile);
+  // DMA it does not see is ordered by the counted waits + barrier of the ring below, as intended.
+  const unsigned long long ubase = (unsigned long long)base;
+  u32x4 rs;
+  rs[0] = __builtin_amdgcn_readfirstlane((unsigned)ubase);
+  rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(ubase >> 32)) & 0xFFFFu;   // stride 0
+  rs[2] = 0x7FFFFFF0u;                                                          // num_records: no clamping wanted
+  rs[3] = 0x00020000u;
+  const int ldb = (int)(ld * sizeof(T));   // bytes per token row (host checks L * ldb < 2^31)
+  int kvo[2], vvo[2], drow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int pslot = (wave * 2 + j) * 64 + lane;
     const int row = pslot >> 3, sl = pslot & 7;
     drow[j] = row;
-    ksrc[j] = base + (long)row * ld + D + (sl ^ xk(row)) * 8;
-    vsrc[j] = base + (long)row * ld + 2 * D + (sl ^ xv(row)) * 8;
+    kvo[j] = row * ldb + (D + (sl ^ xk(row)) * 8) * (int)sizeof(T);
+    vvo[j] = row * ldb + (2 * D + (sl ^ xv(row)) * 8) * (int)sizeof(T);
   }
   int koff[4];
 #pragma unroll
@@ -299,22 +358,29 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   if (last_q > L - 1) last_q = L - 1;
   const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
 
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + wave * 2048;   // LDS byte address of this wave's DMA slots
+  auto dma16 = [&](unsigned lds_addr, int voff_b, int soff_b) {
+    unsigned keep;   // M0 (the DMA's LDS base) is compiler-reserved: save, set, use and restore it in ONE statement
+    // (s_nop 4 first: a descriptor / scalar offset fresh from v_readfirstlane needs 5 wait states before VMEM reads it)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff_b), "s"(rs), "s"(soff_b) : "memory");
+  };
   auto stage = [&](int st, int kt) {
-    char* dst = smem + st * 16384 + wave * 2048;
-    const long step = (long)kt * 64 * ld;
+    const unsigned dst = lds0 + st * 16384;
+    const int so = __builtin_amdgcn_readfirstlane(kt * 64 * ldb);
     if (kt * 64 + 64 <= L) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        glds16(ksrc[j] + step, dst + j * 1024);
-        glds16(vsrc[j] + step, dst + 8192 + j * 1024);
+        dma16(dst + j * 1024, kvo[j], so);
+        dma16(dst + 8192 + j * 1024, vvo[j], so);
       }
-    } else {
+    } else {   // last tile of the key axis: rows beyond L-1 re-read row L-1 (finite data; their scores are masked)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int over = kt * 64 + drow[j] - (L - 1);
         over = over > 0 ? over : 0;
-        glds16(ksrc[j] + step - (long)over * ld, dst + j * 1024);
-        glds16(vsrc[j] + step - (long)over * ld, dst + 8192 + j * 1024);
+        dma16(dst + j * 1024, kvo[j] - over * ldb, so);
+        dma16(dst + 8192 + j * 1024, vvo[j] - over * ldb, so);
       }
     }
   };
@@ -327,25 +393,44 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[qb][db][e] = 0.f;
   float m2[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+  // start values of the S^T accumulator chains: every element = -(the row's reference point m, log2 units).
+  // The empty asm makes the tuples opaque, so they stay 16 live registers instead of 16 v_mov per chain per tile.
+  f32x16 cinit[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[qb][e] = 0.f;
+    asm volatile("" : "+v"(cinit[qb]));
+  }
 
-  auto tile = [&](const char* sb, int kt) {
-    f32x16 s[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[qb][sub][e] = LOG2Q ? -m2[qb] : 0.f;
+  // Exchange between the two 32-lane halves by v_permlane32_swap (swaps lanes 32..63 of its first operand with lanes
+  // 0..31 of its second): fed the same value twice it leaves {lower half's value in every lane, upper half's value in
+  // every lane}.  Inline asm because clang's __builtin_amdgcn_permlane32_swap (ROCm 7.2) returns element 0 of the
+  // intrinsic's result pair for BOTH vector elements (extractvalue ..., 0 twice in the IR): max / sum over ONE half,
+  // silently.  s_nop 1: a VALU-written VGPR needs two wait states before a permlane reads it.
+  auto xhalf_max = [](float a) {   // max over the two 32-lane halves, in every lane
+    float b = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+  };
+  auto xhalf_sum = [](float a) {
+    float b = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+  };
+
+  // S'^T = K . Q^T - m (log2 units) for the 64 keys of a tile and this wave's 64 queries; dead keys -> -inf
+  auto scores = [&](const char* sb, int kt, bool need_mask, f32x16 (&s)[2][2]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       vec8 k0f = *(const vec8*)(sb + koff[ks]);
       vec8 k1f = *(const vec8*)(sb + koff[ks] + 4096);
-      s[0][0] = Elem<T>::mma32(k0f, qf[0][ks], s[0][0]);
-      s[1][0] = Elem<T>::mma32(k0f, qf[1][ks], s[1][0]);
-      s[0][1] = Elem<T>::mma32(k1f, qf[0][ks], s[0][1]);
-      s[1][1] = Elem<T>::mma32(k1f, qf[1][ks], s[1][1]);
+      s[0][0] = Elem<T>::mma32(k0f, qf[0][ks], ks == 0 ? cinit[0] : s[0][0]);
+      s[1][0] = Elem<T>::mma32(k0f, qf[1][ks], ks == 0 ? cinit[1] : s[1][0]);
+      s[0][1] = Elem<T>::mma32(k1f, qf[0][ks], ks == 0 ? cinit[0] : s[0][1]);
+      s[1][1] = Elem<T>::mma32(k1f, qf[1][ks], ks == 0 ? cinit[1] : s[1][1]);
     }
-    if (!LOG2Q) {
+    if (POSTSCALE) {   // chains started at 0 (cinit stays 0): scale to log2 units and subtract m here
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -353,50 +438,30 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 16; ++e) s[qb][sub][e] = fmaf(s[qb][sub][e], LOG2E, -m2[qb]);
     }
-    const int k0 = kt * 64;
-    const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));
-    if (need_mask) {
+    if (need_mask) {   // wave-uniform; the asm statement keeps hipcc from if-converting the branch into 64 selects per tile
+      asm volatile("" ::: "memory");
+      // key index of element e of sub-tile `sub`: k0 + 32 sub + c_e + 4 h with c_e = (e & 3) + 8 (e >> 2).  It is dead
+      // when >= L, or (causal) > the lane's query row: both are "c_e >= thr" for one per-lane threshold, so the
+      // compares take c_e as an inline constant and nothing per element has to stay in registers.
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < 2; ++sub) {
+          const int kb = kt * 64 + sub * 32 + 4 * h;
+          int thr = L - kb;
+          if (causal) thr = min(thr, q0 + qb * 32 + r + 1 - kb);
+          asm volatile("" : "+v"(thr));   // defined HERE: hipcc otherwise hoists the 64 compares out of this branch (and
+                                           // out of the pass loop) onto the path of every tile, SGPR spills included
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            int key = k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            bool dead = (key >= L) || (causal && key > q0 + qb * 32 + r);
-            s[qb][sub][e] = dead ? -INFINITY : s[qb][sub][e];
+            const int ce = (e & 3) + 8 * (e >> 2);
+            s[qb][sub][e] = (ce >= thr) ? -INFINITY : s[qb][sub][e];
           }
+        }
     }
-    float mt[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float a = s[qb][0][0], c = s[qb][1][0];
-#pragma unroll
-      for (int e = 1; e < 16; ++e) {
-        a = fmaxf(a, s[qb][0][e]);
-        c = fmaxf(c, s[qb][1][e]);
-      }
-      a = fmaxf(a, c);
-      mt[qb] = fmaxf(a, __shfl_xor(a, 32, 64));
-    }
-    const bool first = kt == 0;
-    if (first || __any(fmaxf(mt[0], mt[1]) > 0.f)) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-        m2[qb] += delta;
-        l[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[qb][sub][e] -= delta;
-      }
-    }
+  };
+  // p = 2^s in place; rs[qb] = this lane's sum over its 32 keys of the tile
+  auto exps = [&](f32x16 (&s)[2][2], float (&rs)[2]) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       float ra = 0.f, rb = 0.f;
@@ -409,9 +474,72 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
         ra += pa;
         rb += pb;
       }
-      ra += rb;
-      l[qb] += ra + __shfl_xor(ra, 32, 64);
+      rs[qb] = ra + rb;
     }
+  };
+
+  // One key tile.  The running reference point m of a row (cinit = -m) is NOT advanced tile by tile: softmax does
+  // not care which m numerator and denominator share, so the fast path exponentiates against the m the row already
+  // has and never computes a row maximum (49 VALU instructions per tile and a cross-lane exchange + scalar branch in
+  // front of the exponentials).  The stored probabilities must stay convertible to 16 bits, which the row sums --
+  // needed anyway -- police: every p >= 0, so a lane's partial sum <= P_LIMIT bounds each of its p.  A tile that
+  // breaks the bound, or produces a non-finite sum (a score more than 2^127 above m), is redone exactly: scores
+  // recomputed from the LDS tile, true row maxima, m advanced, accumulators re-based.  Tile 0 always takes the
+  // exact path (m starts at 0, not at a maximum).  With random scores the exact path runs once per row of keys.
+  auto tile = [&](const char* sb, int kt, bool need_mask) {
+    f32x16 s[2][2];
+    float rs[2];
+    bool exact = kt == 0;
+#pragma unroll 1
+    for (;;) {   // one pass; a second, exact one only after the fast pass broke the bound (one copy of the code)
+      scores(sb, kt, need_mask, s);
+      if (exact) {
+        asm volatile("" ::: "memory");   // keep this a branch
+        float mt[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          float a = s[qb][0][0], c = s[qb][1][0];
+#pragma unroll
+          for (int e = 1; e < 16; ++e) {
+            a = fmaxf(a, s[qb][0][e]);
+            c = fmaxf(c, s[qb][1][e]);
+          }
+          mt[qb] = xhalf_max(fmaxf(a, c));
+        }
+        const bool first = kt == 0;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          // tile 0: m = the tile's maximum (may be below 0); later: m only ever grows.  A row whose every key so far
+          // is masked (-inf) keeps m where it is.
+          float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
+          delta = delta == -INFINITY ? 0.f : delta;
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m2[qb] += delta;
+          l[qb] *= alpha;
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[qb][sub][e] -= delta;
+            if (!POSTSCALE) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cinit[qb][e] = -m2[qb];
+            asm volatile("" : "+v"(cinit[qb]));
+          }
+        }
+      }
+      exps(s, rs);
+#ifdef AACLIP_MEASURE
+      if (lane == 0) atomicAdd(&g_attn_passes[exact ? (kt == 0 ? 0 : 2) : 1], 1ull);   // [0] tile 0, [1] fast, [2] exact redo
+#endif
+      if (exact || !__any(!(fmaxf(rs[0], rs[1]) <= P_LIMIT))) break;
+      exact = true;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) l[qb] += xhalf_sum(rs[qb]);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -440,25 +568,28 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   stage(0, 0);
   if (nkt > 1) stage(1, 1);
   if (nkt > 2) stage(2, 2);
-#define RING_STEP(i)                                                      \
-  {                                                                       \
-    const int t = kt + (i);                                               \
-    if (t >= nkt) break;                                                  \
-    const int younger = nkt - 1 - t;                                      \
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    \
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
-    __builtin_amdgcn_s_barrier();                                         \
-    if (t + 3 < nkt) stage(((i) + 3) & 3, t + 3);                         \
-    if (active) tile(smem + (i) * 16384, t);                              \
+  // The query fragments were loaded by ordinary global loads hipcc counts; it does not count the DMA above.  Touch
+  // them here so that its wait for them lands HERE (a vmcnt(0) that also covers the prologue DMA) and not inside
+  // the loop, where a vmcnt(small) computed without the DMA in mind would drain the ring every tile.
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+#pragma unroll 1
+  for (int t = 0; t < nkt; ++t) {
+    const int younger = nkt - 1 - t;   // tiles staged after tile t: 4 DMA instructions per wave each
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nkt) stage((t + 3) & 3, t + 3);
+    if (active) {
+      const char* sb = smem + (t & 3) * 16384;
+      const int k0 = t * 64;
+      const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));   // wave-uniform
+      tile(sb, t, need_mask);
+    }
   }
-  for (int kt = 0; kt < nkt; kt += 4) {
-    RING_STEP(0)
-    RING_STEP(1)
-    RING_STEP(2)
-    RING_STEP(3)
-  }
-#undef RING_STEP
 
   if (active) {
 #pragma unroll
@@ -835,6 +966,15 @@ __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ q
   }
 }
 
+#ifdef AACLIP_MEASURE
+void read_attn_passes(unsigned long long* out4, int reset) {
+  (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_passes), 4 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_passes), z, sizeof(z));
+  }
+}
+#endif
 static int g_attn_variant = 0;  // 1 = always the 2-stage 128-row kernel (A/B measurements)
 bool set_attn_variant(int v) {
 #ifdef AACLIP_MEASURE
@@ -863,13 +1003,17 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
     }
 #endif
   } else if (L >= 512 && g_attn_variant != 1) {
-    dim3 g((L + 255) / 256, H, B);
+    const int nqt = (L + 255) / 256;
+    const long total = (long)nqt * H * B;
+    const int per_xcd = (int)((total + 7) / 8);
+    dim3 g((unsigned)(per_xcd * 8));
+    const int tot = (int)total;
     if (dtype == AACLIP_F16) {
-      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<f16, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
-      else hipLaunchKernelGGL((attn16x2_kernel<f16, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<f16, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd);
+      else hipLaunchKernelGGL((attn16x2_kernel<f16, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd);
     } else {
-      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
-      else hipLaunchKernelGGL((attn16x2_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
+      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal, nqt, tot, per_xcd);
+      else hipLaunchKernelGGL((attn16x2_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal, nqt, tot, per_xcd);
     }
   } else {
     dim3 g((L + 127) / 128, H, B);

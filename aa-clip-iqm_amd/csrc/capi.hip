@@ -131,6 +131,15 @@ int aaclip_debug_gemm_stamps(double* out3, int nwaves) {
 #endif
 }
 
+#ifdef AACLIP_MEASURE
+// measurement library only (not declared in include/aaclip.h): how often the long-sequence attention kernel took each
+// of its tile paths since the last reset -- out[0] tile 0, out[1] fast passes, out[2] exact redos
+extern "C" int aaclip_measure_attn_passes(unsigned long long* out4, int reset) {
+  read_attn_passes(out4, reset);
+  return 0;
+}
+#endif
+
 int aaclip_is_measurement_build(void) {
 #ifdef AACLIP_MEASURE
   return 1;
@@ -192,6 +201,8 @@ int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H,
   REQUIRE(qkv && ctx, "attention: null pointer");
   REQUIRE(B > 0 && L > 0 && H > 0, "attention: empty problem");
   REQUIRE(B <= 65535 && H <= 65535, "attention: grid limit");
+  REQUIRE((long)L * 3 * 64 * H * 4 < (1L << 31), "attention: L * 3 * 64 * H * 4 must stay below 2^31 (32-bit row offsets)");
+  REQUIRE((long)((L + 255) / 256) * H * B < (1L << 30), "attention: too many workgroups");
   launch_attention(dtype, qkv, ctx, B, L, H, causal, 0, (hipStream_t)stream);
   return finish("attention");
 }
@@ -374,6 +385,8 @@ int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w,
   REQUIRE(n_blocks >= 1, "block: n_blocks must be positive");
   REQUIRE(B > 0 && L > 0, "block: empty batch");
   REQUIRE(D == 64 * H, "block: D must equal 64*H (head dim 64)");
+  REQUIRE((long)L * 3 * D * 4 < (1L << 31) && (long)B * 3 * D * 4 < (1L << 31),
+          "block: sequence too long for the attention kernel's 32-bit row offsets");
   REQUIRE(F % 128 == 0 && F % 64 == 0, "block: F must be a multiple of 128");
   const char* m = row_width_check(D);
   if (m) return fail(-1, m);

@@ -170,6 +170,33 @@ def test_attention_online_softmax_rescale(dev):
         assert_close(ctx.float(), ref, 3e-3 if code == F16 else 2e-5, 1e-2 if code == F16 else 1e-5, "spike")
 
 
+@pytest.mark.parametrize("causal", [0, 1])
+def test_attention_long_sequence_rebase_paths(dev, causal):
+    """The long-sequence kernel (L >= 512) exponentiates against the reference point a row already has and only
+    re-bases when a tile breaks the 16-bit bound of its probabilities (attention.hip, `tile`): force every path --
+    tile 0 (always exact), quiet tiles (fast), a +40 logit in tile 5 (partial sums beyond the bound -> exact redo), a
+    +150 logit in tile 9 (2^216: the fast pass overflows fp32 to inf -> exact redo), rows with NEGATIVE scores only
+    in tile 0 (m starts below 0), and the ragged last tile."""
+    lib = _lib.load()
+    B, L, H = 2, 700, 2
+    D = 64 * H
+    qkv = synth.randn("t.attn.long", (B * L, 3 * D), 0.5, 8)
+    qkv[:, 0] = 1.0                     # q[:, 0] = 1 in head 0
+    qkv[:64, D] = -6.0                  # keys 0..63 of image 0 (tile 0): logits about -6 for every row
+    qkv[5 * 64 + 7, D] = 40.0           # k[327, 0]: logit +40 (tile 5)
+    qkv[9 * 64 + 30, D] = 150.0         # k[606, 0]: logit +150 (tile 9)
+    qkv[L + 650, D + 64] = 90.0         # image 1, head 1, tile 10 -- with q[:, 64] = 1
+    qkv[L:, 64] = 1.0
+    for code in (F16, BF16):
+        q = qkv.to(TDT[code])
+        ctx = torch.full((B * L, D), float("nan"), dtype=TDT[code], device=dev)
+        qd = q.to(dev)
+        _lib.check(lib.aaclip_attention(code, qd.data_ptr(), ctx.data_ptr(), B, L, H, causal, stream(dev)))
+        ref = _attn_ref(q.float(), B, L, H, causal)
+        tol = (3e-3, 1e-2) if code == F16 else (2.5e-2, 3e-2)
+        assert_close(ctx.float(), ref, tol[0], tol[1], f"long-sequence re-base paths causal={causal} {NAME[code]}")
+
+
 def test_adapter_mix(dev):
     lib = _lib.load()
     x = synth.randn("t.mix.x", (41, 1024), 2.0, 5)

@@ -4,7 +4,8 @@ import argparse, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "aa-clip-iqm_amd"))
 import torch
-os.environ.setdefault("AACLIP_LIB", os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "libaaclip_hip_measure.so"))   # A/B variants live in the measurement library (make measure)
+if "--variant" in sys.argv:   # A/B variants live in the measurement library (make measure); default: the product library
+    os.environ.setdefault("AACLIP_LIB", os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "libaaclip_hip_measure.so"))
 from aaclip_hip import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
