@@ -270,16 +270,29 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 // L2 (before: 2.3 GB fetched per launch for 0.54 GB of q/k/v).
 #ifdef AACLIP_MEASURE
 __device__ unsigned long long g_attn_passes[4];   // measurement library only: tile passes by kind (read_attn_passes)
+// -DATTN_STAMP builds of the measurement library: s_memtime cycles summed per segment of the tile loop, waves 0 and 1
+// of each workgroup: [0] wait + barrier, [1] DMA issue, [2] B1, [3] B2, [4] check 0 (+ rare paths), [5] B3, [6] check 1,
+// [7] B4 + sums, [8] tiles
+__device__ unsigned long long g_attn_stamp[16];   // [9..12]: the DMA instructions of a stage, one by one
 #endif
-template <typename T, bool LOG2Q>
-__global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
+#if defined(AACLIP_MEASURE) && defined(ATTN_STAMP)
+#define STAMP_DECL unsigned long long st_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+#define STAMP_START { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); }
+#define STAMP(i) { unsigned long long st_u; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_u) :: "memory"); st_acc[i] += st_u - st_t; st_t = st_u; }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#endif
+template <typename T, bool LOG2Q, int NW, int PD>
+__global__ __launch_bounds__(NW * 64, 2) void attn16x2_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
                                                           int causal, int nqt, int total, int per_xcd) {
   typedef typename Elem<T>::vec8 vec8;
   typedef typename Elem<T>::vec4 vec4;
   typedef short i16x8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) char smem[65536];  // 4 stages x (K 8K + V 8K)
   constexpr float LOG2E = 1.4426950408889634f;
-  constexpr float P_LIMIT = 32768.f;   // bound of a lane's 32-key partial row sum on the fast path (f16 max 65504)
+  constexpr float P_LIMIT = 32768.f;   // bound of a lane's 16-key partial row sum on the fast path (f16 max 65504)
 
   // XCD-aware numbering: workgroup ids are dealt round-robin over the 8 XCDs, so ids with equal id % 8 share an L2;
   // each XCD walks a contiguous range of (image, head, query block) with the query block fastest
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   const int D = H * 64;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * L * ld + head * 64;
-  const int q0 = qt * 256 + wave * 64;
+  const int q0 = qt * (NW * 64) + wave * 64;
   const bool active = q0 < L;   // wave-uniform: idle waves only feed the ring and the barriers
 
   vec8 qf[2][4];
@@ -331,10 +344,11 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   rs[2] = 0x7FFFFFF0u;                                                          // num_records: no clamping wanted
   rs[3] = 0x00020000u;
   const int ldb = (int)(ld * sizeof(T));   // bytes per token row (host checks L * ldb < 2^31)
-  int kvo[2], vvo[2], drow[2];
+  constexpr int NJ = 8 / NW;   // DMA instructions per wave, tile and operand: 512 slots of 16 B per 64 x 128 B tile
+  int kvo[NJ], vvo[NJ], drow[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int pslot = (wave * 2 + j) * 64 + lane;
+  for (int j = 0; j < NJ; ++j) {
+    const int pslot = (wave * NJ + j) * 64 + lane;
     const int row = pslot >> 3, sl = pslot & 7;
     drow[j] = row;
     kvo[j] = row * ldb + (D + (sl ^ xk(row)) * 8) * (int)sizeof(T);
@@ -354,11 +368,12 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
     }
   }
 
-  int last_q = qt * 256 + 255;
+  int last_q = qt * (NW * 64) + NW * 64 - 1;
   if (last_q > L - 1) last_q = L - 1;
   const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
 
-  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + wave * 2048;   // LDS byte address of this wave's DMA slots
+  STAMP_DECL
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + wave * (NJ * 1024);   // LDS byte address of this wave's DMA slots
   auto dma16 = [&](unsigned lds_addr, int voff_b, int soff_b) {
     unsigned keep;   // M0 (the DMA's LDS base) is compiler-reserved: save, set, use and restore it in ONE statement
     // (s_nop 4 first: a descriptor / scalar offset fresh from v_readfirstlane needs 5 wait states before VMEM reads it)
@@ -370,13 +385,15 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
     const int so = __builtin_amdgcn_readfirstlane(kt * 64 * ldb);
     if (kt * 64 + 64 <= L) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         dma16(dst + j * 1024, kvo[j], so);
+        STAMP(9 + 2 * j)
         dma16(dst + 8192 + j * 1024, vvo[j], so);
+        STAMP(10 + 2 * j)
       }
     } else {   // last tile of the key axis: rows beyond L-1 re-read row L-1 (finite data; their scores are masked)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         int over = kt * 64 + drow[j] - (L - 1);
         over = over > 0 ? over : 0;
         dma16(dst + j * 1024, kvo[j] - over * ldb, so);
@@ -419,155 +436,250 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
     return a + b;
   };
 
-  // S'^T = K . Q^T - m (log2 units) for the 64 keys of a tile and this wave's 64 queries; dead keys -> -inf
-  auto scores = [&](const char* sb, int kt, bool need_mask, f32x16 (&s)[2][2]) {
+  // ---- tile pieces.  A tile = two 32-key sub-tiles; s[qb][sub] holds S'^T = K . Q^T - m (log2 units), later 2^that.
+  // 8 MFMAs: the chains of sub-tile `sub` for both query blocks, started from the -m tuples
+  auto chain = [&](const char* sb, int sub, f32x16 (&s)[2][2]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      vec8 k0f = *(const vec8*)(sb + koff[ks]);
-      vec8 k1f = *(const vec8*)(sb + koff[ks] + 4096);
-      s[0][0] = Elem<T>::mma32(k0f, qf[0][ks], ks == 0 ? cinit[0] : s[0][0]);
-      s[1][0] = Elem<T>::mma32(k0f, qf[1][ks], ks == 0 ? cinit[1] : s[1][0]);
-      s[0][1] = Elem<T>::mma32(k1f, qf[0][ks], ks == 0 ? cinit[0] : s[0][1]);
-      s[1][1] = Elem<T>::mma32(k1f, qf[1][ks], ks == 0 ? cinit[1] : s[1][1]);
-    }
-    if (POSTSCALE) {   // chains started at 0 (cinit stays 0): scale to log2 units and subtract m here
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[qb][sub][e] = fmaf(s[qb][sub][e], LOG2E, -m2[qb]);
-    }
-    if (need_mask) {   // wave-uniform; the asm statement keeps hipcc from if-converting the branch into 64 selects per tile
-      asm volatile("" ::: "memory");
-      // key index of element e of sub-tile `sub`: k0 + 32 sub + c_e + 4 h with c_e = (e & 3) + 8 (e >> 2).  It is dead
-      // when >= L, or (causal) > the lane's query row: both are "c_e >= thr" for one per-lane threshold, so the
-      // compares take c_e as an inline constant and nothing per element has to stay in registers.
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-          const int kb = kt * 64 + sub * 32 + 4 * h;
-          int thr = L - kb;
-          if (causal) thr = min(thr, q0 + qb * 32 + r + 1 - kb);
-          asm volatile("" : "+v"(thr));   // defined HERE: hipcc otherwise hoists the 64 compares out of this branch (and
-                                           // out of the pass loop) onto the path of every tile, SGPR spills included
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int ce = (e & 3) + 8 * (e >> 2);
-            s[qb][sub][e] = (ce >= thr) ? -INFINITY : s[qb][sub][e];
-          }
-        }
+      const vec8 kf = *(const vec8*)(sb + koff[ks] + sub * 4096);
+      s[0][sub] = Elem<T>::mma32(kf, qf[0][ks], ks == 0 ? cinit[0] : s[0][sub]);
+      s[1][sub] = Elem<T>::mma32(kf, qf[1][ks], ks == 0 ? cinit[1] : s[1][sub]);
     }
   };
-  // p = 2^s in place; rs[qb] = this lane's sum over its 32 keys of the tile
-  auto exps = [&](f32x16 (&s)[2][2], float (&rs)[2]) {
+  // dead keys (beyond L, or above the diagonal when causal) -> -inf.  Key index of element e: k0 + 32 sub + c_e + 4 h
+  // with c_e = (e & 3) + 8 (e >> 2); dead <=> c_e >= thr for one per-lane threshold, so the compares take c_e as an
+  // inline constant.  Only called under the wave-uniform need_mask branch.
+  auto mask_sub = [&](int kt, int sub, f32x16 (&s)[2][2]) {
+    asm volatile("" ::: "memory");   // keeps hipcc from if-converting the caller's branch into selects on every tile
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int kb = kt * 64 + sub * 32 + 4 * h;
+      int thr = L - kb;
+      if (causal) thr = min(thr, q0 + qb * 32 + r + 1 - kb);
+      asm volatile("" : "+v"(thr));   // defined HERE: hipcc otherwise hoists the compares onto the path of every tile
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ce = (e & 3) + 8 * (e >> 2);
+        s[qb][sub][e] = (ce >= thr) ? -INFINITY : s[qb][sub][e];
+      }
+    }
+  };
+  // p = 2^s in place for one sub-tile; rs[qb] = this lane's sum over its 16 keys of the sub-tile
+  auto exp_sub = [&](int sub, f32x16 (&s)[2][2], float (&rs)[2]) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       float ra = 0.f, rb = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float pa = __builtin_amdgcn_exp2f(s[qb][0][e]);
-        float pb = __builtin_amdgcn_exp2f(s[qb][1][e]);
-        s[qb][0][e] = pa;
-        s[qb][1][e] = pb;
+      for (int e = 0; e < 16; e += 2) {
+        float xa = s[qb][sub][e], xb = s[qb][sub][e + 1];
+        if (POSTSCALE) {
+          xa = fmaf(xa, LOG2E, -m2[qb]);
+          xb = fmaf(xb, LOG2E, -m2[qb]);
+        }
+        const float pa = __builtin_amdgcn_exp2f(xa), pb = __builtin_amdgcn_exp2f(xb);
+        s[qb][sub][e] = pa;
+        s[qb][sub][e + 1] = pb;
         ra += pa;
         rb += pb;
       }
       rs[qb] = ra + rb;
     }
   };
-
-  // One key tile.  The running reference point m of a row (cinit = -m) is NOT advanced tile by tile: softmax does
-  // not care which m numerator and denominator share, so the fast path exponentiates against the m the row already
-  // has and never computes a row maximum (49 VALU instructions per tile and a cross-lane exchange + scalar branch in
-  // front of the exponentials).  The stored probabilities must stay convertible to 16 bits, which the row sums --
-  // needed anyway -- police: every p >= 0, so a lane's partial sum <= P_LIMIT bounds each of its p.  A tile that
-  // breaks the bound, or produces a non-finite sum (a score more than 2^127 above m), is redone exactly: scores
-  // recomputed from the LDS tile, true row maxima, m advanced, accumulators re-based.  Tile 0 always takes the
-  // exact path (m starts at 0, not at a maximum).  With random scores the exact path runs once per row of keys.
-  auto tile = [&](const char* sb, int kt, bool need_mask) {
-    f32x16 s[2][2];
-    float rs[2];
-    bool exact = kt == 0;
-#pragma unroll 1
-    for (;;) {   // one pass; a second, exact one only after the fast pass broke the bound (one copy of the code)
-      scores(sb, kt, need_mask, s);
-      if (exact) {
-        asm volatile("" ::: "memory");   // keep this a branch
-        float mt[2];
+  // Exact treatment of sub-tile `sub` (rare, out of line): scores recomputed from the LDS tile, true row maxima, the
+  // reference point m advanced, everything that is still expressed against the old m re-based: O, l, the pending
+  // partial sums of sub-tile 0 (`pend`, when sub == 1), the scores of sub-tile 1 that are already computed but not
+  // yet exponentiated (when sub == 0).  Then the sub-tile is exponentiated again.
+  auto rebase = [&](const char* sb, int kt, int sub, bool need_mask, f32x16 (&s)[2][2], float (&rs)[2], float* pend) {
+    asm volatile("" ::: "memory");
+    chain(sb, sub, s);
+    if (need_mask) mask_sub(kt, sub, s);
+    const bool first = kt == 0 && sub == 0;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          float a = s[qb][0][0], c = s[qb][1][0];
+    for (int qb = 0; qb < 2; ++qb) {
+      float a = s[qb][sub][0];
 #pragma unroll
-          for (int e = 1; e < 16; ++e) {
-            a = fmaxf(a, s[qb][0][e]);
-            c = fmaxf(c, s[qb][1][e]);
-          }
-          mt[qb] = xhalf_max(fmaxf(a, c));
+      for (int e = 1; e < 16; ++e) a = fmaxf(a, s[qb][sub][e]);
+      if (POSTSCALE) a = fmaf(a, LOG2E, -m2[qb]);
+      const float mt = xhalf_max(a);
+      // very first sub-tile: m = its maximum (may be below 0); later m only ever grows.  A row whose every key so
+      // far is masked (-inf) keeps m where it is.
+      float delta = first ? mt : fmaxf(mt, 0.f);
+      delta = delta == -INFINITY ? 0.f : delta;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m2[qb] += delta;
+      l[qb] *= alpha;
+      if (pend) pend[qb] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
+      if (!POSTSCALE) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[qb][sub][e] -= delta;
+        if (sub == 0) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[qb][1][e] -= delta;
         }
-        const bool first = kt == 0;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          // tile 0: m = the tile's maximum (may be below 0); later: m only ever grows.  A row whose every key so far
-          // is masked (-inf) keeps m where it is.
-          float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
-          delta = delta == -INFINITY ? 0.f : delta;
-          const float alpha = __builtin_amdgcn_exp2f(-delta);
-          m2[qb] += delta;
-          l[qb] *= alpha;
-#pragma unroll
-          for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
-#pragma unroll
-          for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[qb][sub][e] -= delta;
-            if (!POSTSCALE) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cinit[qb][e] = -m2[qb];
-            asm volatile("" : "+v"(cinit[qb]));
-          }
-        }
+        for (int e = 0; e < 16; ++e) cinit[qb][e] = -m2[qb];
+        asm volatile("" : "+v"(cinit[qb]));
       }
-      exps(s, rs);
-#ifdef AACLIP_MEASURE
-      if (lane == 0) atomicAdd(&g_attn_passes[exact ? (kt == 0 ? 0 : 2) : 1], 1ull);   // [0] tile 0, [1] fast, [2] exact redo
-#endif
-      if (exact || !__any(!(fmaxf(rs[0], rs[1]) <= P_LIMIT))) break;
-      exact = true;
     }
+    exp_sub(sub, s, rs);
+  };
+  auto vread = [&](const char* sb, int sub, int s2, int db) {   // V^T fragment: 32 d x 16 keys, transposed LDS read
+    const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
+    i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
+    i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
+    i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(vec8, both);
+  };
+  auto kread = [&](const char* sb, int sub, int ks) { return *(const vec8*)(sb + koff[ks] + sub * 4096); };
+  auto pcvt = [&](const f32x16& p, int s2) {   // 8 probabilities of one (query block, 16-key step) -> MFMA B operand
+    vec8 pf;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) l[qb] += xhalf_sum(rs[qb]);
+    for (int j = 0; j < 8; ++j) pf[j] = from_float<T>(p[8 * s2 + j]);
+    return pf;
+  };
+  // 2^s in place for elements [4c, 4c+4) of sub-tile `sub`, both query blocks (8 v_exp), sums into acc[qb][0..1]
+  auto exp_chunk = [&](int sub, int c, f32x16 (&s)[2][2], float (&acc)[2][2]) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        vec8 vf[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
-          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
-          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
-          i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          vf[db] = __builtin_bit_cast(vec8, both);
-        }
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          vec8 pf;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = from_float<T>(s[qb][sub][8 * s2 + j]);
-          o[qb][0] = Elem<T>::mma32(vf[0], pf, o[qb][0]);
-          o[qb][1] = Elem<T>::mma32(vf[1], pf, o[qb][1]);
-        }
+      for (int e = 4 * c; e < 4 * c + 4; ++e) {
+        float x = s[qb][sub][e];
+        if (POSTSCALE) x = fmaf(x, LOG2E, -m2[qb]);
+        const float pe = __builtin_amdgcn_exp2f(x);
+        s[qb][sub][e] = pe;
+        acc[qb][e & 1] += pe;
       }
   };
+#define SB0 __builtin_amdgcn_sched_barrier(0)
 
-  // ring prologue: up to three tiles in flight
+  // One key tile, software-pipelined at sub-tile granularity INSIDE the wave: on this chip VALU work hides in the
+  // shadow of the SAME wave's MFMAs, hardly in its SIMD partner's, so the MFMAs of one step are
+  // issued between the exponentials of the step before it, in chunks of 2 MFMAs + 8 v_exp + 8 adds pinned by
+  // sched_barrier (hipcc's own order clusters the MFMAs; sched_group_barrier patterns were not honoured):
+  //   B1  S(sub 0) chains                                               8 MFMA
+  //   B2  S(sub 1) chains  ||  2^S(sub 0), its partial row sums         4 x (2 MFMA, 8 v_exp, 8 add)
+  //   B3  O += V0 . P0     ||  2^S(sub 1), partial sums, P conversions  4 x (2 MFMA, 8 v_exp, 8 add, 4 cvt)
+  //   B4  O += V1 . P1     ||  P conversions, l += sums                 4 x (2 MFMA, 4 cvt)
+  // The reference point m of a row (cinit = -m) is NOT advanced tile by tile: softmax does not care which m numerator
+  // and denominator share, so the fast path exponentiates against the m the row already has and never computes a row
+  // maximum.  The stored probabilities must stay convertible to 16 bits, which the row sums -- needed anyway --
+  // police: every p >= 0, so a lane's partial sum <= P_LIMIT bounds each of its p.  A sub-tile that breaks the bound,
+  // or produces a non-finite sum (a score more than 2^127 above m), is redone exactly BEFORE its probabilities are
+  // converted or multiplied into O (rebase).  The very first sub-tile of a row always takes the exact path (m starts
+  // at 0, not at a maximum).  With the synthetic tower 0.9 % of the sub-tiles are redone.
+  auto tile = [&](const char* sb, int kt, bool need_mask) {
+    f32x16 s[2][2];
+    float rs0[2], rs1[2];
+    // ---- B1
+    {
+      vec8 kf = kread(sb, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const vec8 kn = ks < 3 ? kread(sb, 0, ks + 1) : kread(sb, 1, 0);
+        s[0][0] = Elem<T>::mma32(kf, qf[0][ks], ks == 0 ? cinit[0] : s[0][0]);
+        s[1][0] = Elem<T>::mma32(kf, qf[1][ks], ks == 0 ? cinit[1] : s[1][0]);
+        kf = kn;
+      }
+      if (need_mask) mask_sub(kt, 0, s);
+      SB0;
+      STAMP(2)
+      // ---- B2
+      float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        vec8 kn = kf;
+        if (ks < 3) kn = kread(sb, 1, ks + 1);
+        s[0][1] = Elem<T>::mma32(kf, qf[0][ks], ks == 0 ? cinit[0] : s[0][1]);
+        s[1][1] = Elem<T>::mma32(kf, qf[1][ks], ks == 0 ? cinit[1] : s[1][1]);
+        exp_chunk(0, ks, s, acc);
+        kf = kn;
+        SB0;
+      }
+      rs0[0] = acc[0][0] + acc[0][1];
+      rs0[1] = acc[1][0] + acc[1][1];
+    }
+    // (the ballot is evaluated on every tile, tile 0 included: written as `kt == 0 || ...` hipcc sees that tile 0 does
+    //  not need the exponentials above and sinks them out of B2, away from the MFMAs they are meant to hide behind)
+    STAMP(3)
+    const bool bad0 = __any(!(fmaxf(rs0[0], rs0[1]) <= P_LIMIT));
+    if ((kt == 0) | bad0) rebase(sb, kt, 0, need_mask, s, rs0, nullptr);
+    if (need_mask) mask_sub(kt, 1, s);
+    SB0;
+    STAMP(4)
+    // ---- B3   (chunk g: 16-key step s2 = g >> 1 of sub-tile 0, query block qb = g & 1)
+    vec8 v1a[2];   // first V^T fragments of sub-tile 1, prefetched in B3 for B4
+    {
+      vec8 va[2] = {vread(sb, 0, 0, 0), vread(sb, 0, 0, 1)};
+      vec8 vb[2];
+      vec8 pf = pcvt(s[0][0], 0);
+      float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+      SB0;
+      vb[0] = vread(sb, 0, 1, 0);                                // g = 0
+      vb[1] = vread(sb, 0, 1, 1);
+      o[0][0] = Elem<T>::mma32(va[0], pf, o[0][0]);
+      o[0][1] = Elem<T>::mma32(va[1], pf, o[0][1]);
+      pf = pcvt(s[1][0], 0);
+      exp_chunk(1, 0, s, acc);
+      SB0;
+      o[1][0] = Elem<T>::mma32(va[0], pf, o[1][0]);              // g = 1
+      o[1][1] = Elem<T>::mma32(va[1], pf, o[1][1]);
+      pf = pcvt(s[0][0], 1);
+      exp_chunk(1, 1, s, acc);
+      SB0;
+      v1a[0] = vread(sb, 1, 0, 0);                               // g = 2
+      v1a[1] = vread(sb, 1, 0, 1);
+      o[0][0] = Elem<T>::mma32(vb[0], pf, o[0][0]);
+      o[0][1] = Elem<T>::mma32(vb[1], pf, o[0][1]);
+      pf = pcvt(s[1][0], 1);
+      exp_chunk(1, 2, s, acc);
+      SB0;
+      o[1][0] = Elem<T>::mma32(vb[0], pf, o[1][0]);              // g = 3
+      o[1][1] = Elem<T>::mma32(vb[1], pf, o[1][1]);
+      exp_chunk(1, 3, s, acc);
+      SB0;
+      rs1[0] = acc[0][0] + acc[0][1];
+      rs1[1] = acc[1][0] + acc[1][1];
+    }
+    STAMP(5)
+    const bool bad1 = __any(!(fmaxf(rs1[0], rs1[1]) <= P_LIMIT));
+    if (bad1) rebase(sb, kt, 1, need_mask, s, rs1, rs0);
+    SB0;
+    STAMP(6)
+    // ---- B4
+    {
+      vec8 v1b[2];
+      vec8 pf = pcvt(s[0][1], 0);
+      v1b[0] = vread(sb, 1, 1, 0);                               // g = 0
+      v1b[1] = vread(sb, 1, 1, 1);
+      o[0][0] = Elem<T>::mma32(v1a[0], pf, o[0][0]);
+      o[0][1] = Elem<T>::mma32(v1a[1], pf, o[0][1]);
+      pf = pcvt(s[1][1], 0);
+      SB0;
+      o[1][0] = Elem<T>::mma32(v1a[0], pf, o[1][0]);             // g = 1
+      o[1][1] = Elem<T>::mma32(v1a[1], pf, o[1][1]);
+      pf = pcvt(s[0][1], 1);
+      SB0;
+      o[0][0] = Elem<T>::mma32(v1b[0], pf, o[0][0]);             // g = 2
+      o[0][1] = Elem<T>::mma32(v1b[1], pf, o[0][1]);
+      pf = pcvt(s[1][1], 1);
+      SB0;
+      o[1][0] = Elem<T>::mma32(v1b[0], pf, o[1][0]);             // g = 3
+      o[1][1] = Elem<T>::mma32(v1b[1], pf, o[1][1]);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) l[qb] += xhalf_sum(rs0[qb] + rs1[qb]);
+    STAMP(7)
+  };
+#undef SB0
+
+  // ring prologue: PD tiles in flight (PD = prefetch distance in tiles, 1..3; 4 LDS stages)
   stage(0, 0);
-  if (nkt > 1) stage(1, 1);
-  if (nkt > 2) stage(2, 2);
+  if (PD > 1 && nkt > 1) stage(1, 1);
+  if (PD > 2 && nkt > 2) stage(2, 2);
   // The query fragments were loaded by ordinary global loads hipcc counts; it does not count the DMA above.  Touch
   // them here so that its wait for them lands HERE (a vmcnt(0) that also covers the prologue DMA) and not inside
   // the loop, where a vmcnt(small) computed without the DMA in mind would drain the ring every tile.
@@ -575,14 +687,27 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+  STAMP_START
 #pragma unroll 1
   for (int t = 0; t < nkt; ++t) {
-    const int younger = nkt - 1 - t;   // tiles staged after tile t: 4 DMA instructions per wave each
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // tiles already staged behind tile t stay in flight: 2 * NJ DMA instructions per wave each
+    int younger = nkt - 1 - t;
+    younger = younger < PD - 1 ? younger : PD - 1;
+#if defined(AACLIP_MEASURE) && defined(ATTN_NODMA)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    if (younger >= 2) { if (NJ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (younger == 1) { if (NJ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
-    if (t + 3 < nkt) stage((t + 3) & 3, t + 3);
+    STAMP(0)
+#if defined(AACLIP_MEASURE) && defined(ATTN_NODMA)
+    if (t + PD < nkt && t < 1) stage((t + PD) & 3, t + PD);   // timing ablation (WRONG RESULTS): the ring is filled once
+#else
+    if (t + PD < nkt) stage((t + PD) & 3, t + PD);
+#endif
+    STAMP(1)
     if (active) {
       const char* sb = smem + (t & 3) * 16384;
       const int k0 = t * 64;
@@ -591,6 +716,13 @@ __global__ __launch_bounds__(256, 2) void attn16x2_kernel(const T* __restrict__ 
     }
   }
 
+#if defined(AACLIP_MEASURE) && defined(ATTN_STAMP)
+  if (active && (wave & 3) < 2 && lane == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_attn_stamp[i], st_acc[i]);
+    for (int i = 9; i < 13; ++i) atomicAdd(&g_attn_stamp[i], st_acc[i]);
+    atomicAdd(&g_attn_stamp[8], (unsigned long long)nkt);
+  }
+#endif
   if (active) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -974,11 +1106,22 @@ void read_attn_passes(unsigned long long* out4, int reset) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_passes), z, sizeof(z));
   }
 }
+void read_attn_stamps(unsigned long long* out9, int reset) {
+  (void)hipMemcpyFromSymbol(out9, HIP_SYMBOL(g_attn_stamp), 13 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), z, sizeof(z));
+  }
+}
+#endif
+#ifndef ATTN_PD
+#define ATTN_PD 2   // prefetch distance of the long-sequence kernel's K/V ring, in tiles (1, 2, 3 measured alike;
+                    // beyond ~8 DMA instructions in flight per wave their ISSUE starts to block: tools/ldsdma_probe.hip)
 #endif
 static int g_attn_variant = 0;  // 1 = always the 2-stage 128-row kernel (A/B measurements)
 bool set_attn_variant(int v) {
 #ifdef AACLIP_MEASURE
-  const bool ok = v >= 0 && v <= 2;
+  const bool ok = v >= 0 && v <= 3;   // 2 = software-pipelined 128-query kernel, 3 = long-sequence kernel with 8-wave workgroups
 #else
   const bool ok = v == 0 || v == 1;
 #endif
@@ -1003,18 +1146,30 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
     }
 #endif
   } else if (L >= 512 && g_attn_variant != 1) {
-    const int nqt = (L + 255) / 256;
+    // 256 queries (4 waves) per workgroup, two workgroups per CU.  512 queries in one 8-wave workgroup halve the K/V
+    // bytes a CU streams, and measured the same (0.699 vs 0.703 ms): kept as variant 3 of the measurement library.
+#ifdef AACLIP_MEASURE
+    const int nw = g_attn_variant == 3 ? 8 : 4;
+#else
+    const int nw = 4;
+#endif
+    const int nqt = (L + nw * 64 - 1) / (nw * 64);
     const long total = (long)nqt * H * B;
     const int per_xcd = (int)((total + 7) / 8);
-    dim3 g((unsigned)(per_xcd * 8));
+    dim3 g((unsigned)(per_xcd * 8)), blk(nw * 64);
     const int tot = (int)total;
-    if (dtype == AACLIP_F16) {
-      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<f16, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd);
-      else hipLaunchKernelGGL((attn16x2_kernel<f16, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd);
-    } else {
-      if (log2q) hipLaunchKernelGGL((attn16x2_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal, nqt, tot, per_xcd);
-      else hipLaunchKernelGGL((attn16x2_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal, nqt, tot, per_xcd);
+#define ATTN_LAUNCH(TT, LQ, NWV) hipLaunchKernelGGL((attn16x2_kernel<TT, LQ, NWV, ATTN_PD>), g, blk, 0, s, (const TT*)qkv, (TT*)ctx, L, H, causal, nqt, tot, per_xcd)
+#ifdef AACLIP_MEASURE
+    if (nw == 8) {
+      if (dtype == AACLIP_F16) { if (log2q) ATTN_LAUNCH(f16, true, 8); else ATTN_LAUNCH(f16, false, 8); }
+      else { if (log2q) ATTN_LAUNCH(bf16, true, 8); else ATTN_LAUNCH(bf16, false, 8); }
+    } else
+#endif
+    {
+      if (dtype == AACLIP_F16) { if (log2q) ATTN_LAUNCH(f16, true, 4); else ATTN_LAUNCH(f16, false, 4); }
+      else { if (log2q) ATTN_LAUNCH(bf16, true, 4); else ATTN_LAUNCH(bf16, false, 4); }
     }
+#undef ATTN_LAUNCH
   } else {
     dim3 g((L + 127) / 128, H, B);
     if (dtype == AACLIP_F16) {

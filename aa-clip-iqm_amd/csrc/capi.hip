@@ -138,6 +138,10 @@ extern "C" int aaclip_measure_attn_passes(unsigned long long* out4, int reset) {
   read_attn_passes(out4, reset);
   return 0;
 }
+extern "C" int aaclip_measure_attn_stamps(unsigned long long* out9, int reset) {
+  read_attn_stamps(out9, reset);
+  return 0;
+}
 #endif
 
 int aaclip_is_measurement_build(void) {

@@ -481,7 +481,10 @@ def test_auroc_parity_on_synthetic_masks(dev, full_weights):
     err = (amap.double() - omap.double()).abs()
     print(f"fused anomaly map vs oracle: max |err| {err.max().item():.3e}, rms {err.pow(2).mean().sqrt().item():.3e}, "
           f"max share of 1e-3+1e-2|ref| {(err / (1e-3 + 1e-2 * omap.double().abs())).max().item():.2f}")
-    assert_close(amap, omap, 6e-3, 1e-2, "anomaly map (x100 cosines, fp16 towers on both sides of the dot)")
+    # measured on MI355X over the 1.07 M pixels: rms 2.0e-3, max 8.3e-3 (4.2 sigma; it moves by +-30 % with any change
+    # of summation order in the tower).  Asserted at 1.2e-2 + 1e-2 |ref| (6 sigma); what the metric needs is below.
+    assert_close(amap, omap, 1.2e-2, 1e-2, "anomaly map (x100 cosines, fp16 towers on both sides of the dot)")
+    assert err.pow(2).mean().sqrt().item() < 3e-3
     a = roc_auc_score(masks.reshape(-1), amap.numpy().reshape(-1))
     b = roc_auc_score(masks.reshape(-1), omap.numpy().reshape(-1))
     assert abs(a - b) <= 1e-3, (a, b)
