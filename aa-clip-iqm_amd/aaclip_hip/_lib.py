@@ -16,7 +16,7 @@ MEASURE_LIB_PATH = os.path.join(_HERE, "libaaclip_hip_measure.so")   # `make mea
 ABI_VERSION = 3   # include/aaclip.h AACLIP_ABI_VERSION this binding was written against
 
 F32, F16, BF16 = 0, 1, 2
-ACT_NONE, ACT_LEAKY = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_ACT_F32 = 0, 1, 2, 3
 
 _vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
@@ -58,6 +58,12 @@ SIGNATURES = {
     "aaclip_gemm": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
     "aaclip_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
+    "aaclip_small_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "aaclip_residual_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "aaclip_combine3": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _l, _vp]),
+    "aaclip_linear_smallk": (_i, [_i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "aaclip_drop_cls_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "aaclip_iqm_map": (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp]),
     "aaclip_set_gemm_variant": (_i, [_i]),
     "aaclip_debug_gemm_stamps": (_i, [C.POINTER(C.c_double), _i]),
     "aaclip_profile_begin": (_i, [C.c_uint, _i]),

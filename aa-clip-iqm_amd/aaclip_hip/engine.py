@@ -478,3 +478,90 @@ def preprocess(src_u8: torch.Tensor, img_size: int, mean=CLIP_MEAN, std=CLIP_STD
                                              vb.data_ptr(), vk.data_ptr(), lut.data_ptr(), out.data_ptr(),
                                              _stream(dev)), "preprocess")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# IQM side branch (reference model/iqm.py, model/adapter.py:186-269, test_last.py:102-147): thin wrappers of the C ABI
+def gemm(code: int, epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+         act: int = 0) -> torch.Tensor:
+    """aaclip_gemm on prepared operands: a [M, K] and w [N, K] in the compute dtype, bias fp32 [N] or None,
+    out [M, N] (16-bit for EPI_BIAS / EPI_BIAS_GELU, fp32 for EPI_ACT_F32)."""
+    M, K = a.shape
+    N = w.shape[0]
+    _lib.check(_lib.load().aaclip_gemm(code, epi, a.data_ptr(), K, w.data_ptr(), _ptr(bias), out.data_ptr(), N, M, N, K,
+                                       int(act), 0, 1.0, _stream(a.device)), "gemm")
+    return out
+
+
+def small_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nq: int, Lk: int, heads: int,
+                    kv_code: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(hd)) v for a handful of queries (reference model/iqm.py:108-139).  q fp32 [B*nq, D];
+    k, v [B*Lk, D] in the kv dtype -> fp32 [B*nq, D]."""
+    D = q.shape[-1]
+    hd = D // heads
+    out = torch.empty(B * nq, D, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().aaclip_small_attention(kv_code, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, nq,
+                                                  Lk, heads, hd, 1.0 / (hd ** 0.5), _stream(q.device)), "small_attention")
+    return out
+
+
+def residual_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], ln, eps: float) -> torch.Tensor:
+    """LayerNorm(a + b) (reference model/iqm.py:150-154); fp32 [rows, D]."""
+    rows, D = a.shape
+    out = torch.empty_like(a)
+    w, bias = _f32c(ln.weight), _f32c(ln.bias)
+    _lib.check(_lib.load().aaclip_residual_layernorm(a.data_ptr(), _ptr(b), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                     rows, D, float(eps), _stream(a.device)), "residual_layernorm")
+    return out
+
+
+def combine3(a: torch.Tensor, b: Optional[torch.Tensor], c: Optional[torch.Tensor], wa: float, wb: float,
+             wc: float) -> torch.Tensor:
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().aaclip_combine3(a.data_ptr(), _ptr(b), _ptr(c), float(wa), float(wb), float(wc), out.data_ptr(),
+                                           a.numel(), _stream(a.device)), "combine3")
+    return out
+
+
+def linear_smallk(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out_code: int) -> torch.Tensor:
+    """y = x W^T + b for in_features <= 4 -> [R, N] in the compute dtype."""
+    x = _f32c(x)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    w, b = _f32c(weight), (_f32c(bias) if bias is not None else None)
+    out = torch.empty(x2.shape[0], w.shape[0], dtype=_TORCH_DT[out_code], device=x.device)
+    _lib.check(_lib.load().aaclip_linear_smallk(out_code, x2.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), x2.shape[0],
+                                                w.shape[0], K, _stream(x.device)), "linear_smallk")
+    return out
+
+
+def drop_cls_rows(src: torch.Tensor, dst: torch.Tensor, B: int, L: int, row_off: int, code: int) -> None:
+    """src [B*L, E] -> rows 1.. of every image into dst [B, rows_per_image, E] at row_off."""
+    E = src.shape[-1]
+    _lib.check(_lib.load().aaclip_drop_cls_rows(code, src.data_ptr(), dst.data_ptr(), B, L, E, dst.shape[1], row_off,
+                                                _stream(src.device)), "drop_cls_rows")
+
+
+def iqm_map(seg_tokens: Sequence[torch.Tensor], queries: torch.Tensor, img_size: int, base: Optional[torch.Tensor] = None,
+            w_base: float = 0.0, w_iqm: float = 1.0) -> torch.Tensor:
+    """reference test_last.py:102-147 -> [B, S, S] = w_base * base + w_iqm * sum over levels of the upsampled
+    sigmoid(cos(f, q_abnormal) - cos(f, q_normal))."""
+    lib = _lib.load()
+    segs = [_f32c(s) for s in seg_tokens]
+    require_gpu(segs[0], "iqm_map")
+    B, P, E = segs[0].shape
+    g = int(round(P ** 0.5))
+    if g * g != P:
+        raise AssertionError(f"L={P} is not a perfect square")         # reference test_last.py:125
+    q = _f32c(queries)
+    if q.shape != (B, 2, E):
+        raise ValueError("queries must be [B, 2, E] (normal, abnormal)")
+    out = torch.empty(B, img_size, img_size, dtype=torch.float32, device=segs[0].device)
+    bs = _f32c(base) if base is not None else None
+    if bs is not None and bs.shape != out.shape:
+        raise ValueError("base map must be [B, S, S]")
+    ws = Workspace.get(segs[0].device, len(segs) * B * P * 4 + 256)
+    arr = (C.c_void_p * len(segs))(*[s.data_ptr() for s in segs])
+    _lib.check(lib.aaclip_iqm_map(arr, len(segs), q.data_ptr(), _ptr(bs), out.data_ptr(), B, g, E, img_size, float(w_base),
+                                  float(w_iqm), ws.data_ptr(), ws.numel(), _stream(out.device)), "iqm_map")
+    return out

@@ -166,6 +166,59 @@ def synth_text_adapter_state_dict(cfg: ClipCfg, until: int = 3, seed: int = 111)
     return sd
 
 
+def synth_iqm_state_dict(cfg: ClipCfg, levels: int = 4, relu: bool = False, hidden: int = 768, layers: int = 2,
+                         inter: int = 2048, seed: int = 111) -> Dict[str, torch.Tensor]:
+    """Seeded weights of everything the IQM side branch owns, under the reference's parameter names relative to
+    AdaptedCLIP (reference model/adapter.py:56-92, model/iqm.py): `iqm.*`, `class_query_mlp.{0,2}.*`,
+    `query_adapters.{i}.fc[.0].weight`, `iqm_layer_norm.*`, `pos_embedding`, `visual_weight`, `text_weight`, plus the
+    two projections the reference creates lazily with fresh random weights on the first forward and never saves
+    (`visual_feature_proj` Linear(hidden, hidden), adapter.py:213-218; `text_feature_proj` Linear(2, 768) -- 2 because
+    the anchors arrive as [B, 768, 2], adapter.py:229-243): here they are ordinary seeded parameters.
+    Linear weights xavier-uniform like the reference's _init_weights_ (:107-123), biases and LayerNorm affine
+    parameters non-trivial so those paths are exercised."""
+    dv = cfg.vision.width
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out_f, in_f, bias=True):
+        sd[name + ".weight"] = _xavier("iqm_branch." + name, out_f, in_f, seed)
+        if bias:
+            sd[name + ".bias"] = randn("iqm_branch." + name + ".bias", (out_f,), 0.05, seed)
+
+    def ln(name, d):
+        sd[name + ".weight"] = randn("iqm_branch." + name + ".w", (d,), 0.1, seed, 1.0)
+        sd[name + ".bias"] = randn("iqm_branch." + name + ".b", (d,), 0.05, seed)
+
+    lin("class_query_mlp.0", hidden, dv)
+    lin("class_query_mlp.2", hidden, hidden)
+    for i in range(levels):
+        k = f"query_adapters.{i}." + ("fc.0" if relu else "fc")
+        sd[k + ".weight"] = _xavier("iqm_branch." + k, hidden, dv, seed)
+    lin("visual_feature_proj", hidden, hidden)
+    lin("text_feature_proj", 768, 2)
+    ln("iqm_layer_norm", hidden)
+    ln("iqm.layernorm", hidden)
+    for l in range(layers):
+        p = f"iqm.encoder.layer.{l}."
+        for att in ("attention", "crossattention", "text_crossattention"):
+            for m in ("query", "key", "value"):
+                lin(p + att + ".attention." + m, hidden, hidden)
+            lin(p + att + ".output.dense", hidden, hidden)
+            ln(p + att + ".output.LayerNorm", hidden)
+        for suffix in ("", "_query"):
+            lin(p + "intermediate" + suffix + ".dense", inter, hidden)
+            lin(p + "output" + suffix + ".dense", hidden, inter)
+            ln(p + "output" + suffix + ".LayerNorm", hidden)
+    pos = torch.arange(512, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, hidden, 2, dtype=torch.float32) * (-math.log(10000.0) / hidden))
+    pe = torch.zeros(512, hidden)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    sd["pos_embedding"] = pe.unsqueeze(0)          # [1, 512, hidden], reference adapter.py:98-105
+    sd["visual_weight"] = torch.tensor(0.6)
+    sd["text_weight"] = torch.tensor(0.4)
+    return sd
+
+
 def synth_images(batch: int, size: int, seed: int = 111, offset: int = 0) -> torch.Tensor:
     """CLIP-normalised pixels are ~N(0,1); image i only depends on
     (seed, offset+i) so any rank can regenerate its shard."""

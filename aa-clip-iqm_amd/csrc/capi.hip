@@ -219,6 +219,70 @@ int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight,
   return finish("adapter_mix");
 }
 
+int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
+                           int H, int hd, float scale, void* stream) {
+  REQUIRE(dtype_ok(kv_dtype), "small_attention: bad dtype");
+  REQUIRE(q && k && v && out, "small_attention: null pointer");
+  REQUIRE(B > 0 && B <= 65535 && H <= 65535, "small_attention: bad batch / heads");
+  const char* m = small_attention_check(nq, Lk, H, hd);
+  if (m) return fail(-1, m);
+  launch_small_attention(kv_dtype, q, k, v, out, B, nq, Lk, H, hd, scale, (hipStream_t)stream);
+  return finish("small_attention");
+}
+
+int aaclip_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,
+                              int D, float eps, void* stream) {
+  REQUIRE(a && w && bias && out, "residual_layernorm: null pointer");
+  REQUIRE(rows > 0 && D > 0 && D % 64 == 0 && D <= 4096, "residual_layernorm: D must be a multiple of 64, <= 4096");
+  launch_residual_layernorm(a, b, w, bias, out, rows, D, eps, (hipStream_t)stream);
+  return finish("residual_layernorm");
+}
+
+int aaclip_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, long n,
+                    void* stream) {
+  REQUIRE(a && out && n > 0, "combine3: bad arguments");
+  launch_combine3(a, b, c, wa, wb, wc, out, n, (hipStream_t)stream);
+  return finish("combine3");
+}
+
+int aaclip_linear_smallk(int out_dtype, const float* x, const float* W, const float* bias, void* y, long R, int N, int K,
+                         void* stream) {
+  REQUIRE(dtype_ok(out_dtype), "linear_smallk: bad dtype");
+  REQUIRE(x && W && y, "linear_smallk: null pointer");
+  REQUIRE(R > 0 && N > 0 && K >= 1 && K <= 4, "linear_smallk: in_features must be 1..4");
+  launch_linear_smallk(out_dtype, x, W, bias, y, R, N, K, (hipStream_t)stream);
+  return finish("linear_smallk");
+}
+
+int aaclip_drop_cls_rows(int dtype, const void* src, void* dst, int B, int L, int E, int rows_per_image, int row_off,
+                         void* stream) {
+  REQUIRE(dtype_ok(dtype), "drop_cls_rows: bad dtype");
+  REQUIRE(src && dst, "drop_cls_rows: null pointer");
+  REQUIRE(B > 0 && L > 1 && E > 0 && E % 8 == 0, "drop_cls_rows: E must be a multiple of 8");
+  REQUIRE(row_off >= 0 && row_off + (L - 1) <= rows_per_image, "drop_cls_rows: rows do not fit the destination");
+  launch_drop_cls_rows(dtype, src, dst, B, L, E, rows_per_image, row_off, (hipStream_t)stream);
+  return finish("drop_cls_rows");
+}
+
+int aaclip_iqm_map(const float* const* seg, int NL, const float* queries, const float* base, float* out, int B, int g,
+                   int E, int S, float w_base, float w_iqm, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(seg && queries && out && ws, "iqm_map: null pointer");
+  REQUIRE(NL >= 1 && NL <= 4, "iqm_map: 1..4 levels");
+  REQUIRE(B > 0 && B <= 65535 && g >= 1 && g <= 40 && S >= 1, "iqm_map: bad shape (grid <= 40)");
+  const char* m = row_width_check(E);
+  if (m) return fail(-1, m);
+  const int P = g * g;
+  REQUIRE(ws_bytes >= (size_t)NL * B * P * 4, "iqm_map: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* grids = (float*)ws;
+  for (int l = 0; l < NL; ++l) {
+    REQUIRE(seg[l], "iqm_map: null level pointer");
+    launch_iqm_scores(seg[l], queries, grids + (size_t)l * B * P, B, P, E, s);
+  }
+  launch_iqm_upsample(grids, base, out, B, g, S, NL, w_base, w_iqm, s);
+  return finish("iqm_map");
+}
+
 int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, const float* pos,
                        const float* ln_pre_w, const float* ln_pre_b, float* x, int B, int H, int W, int ps, int D,
                        int dtype, void* ws, size_t ws_bytes, void* stream) {

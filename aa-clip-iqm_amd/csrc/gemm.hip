@@ -38,6 +38,7 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
   } else if (EPI == EPI_ACT_F32) {
     if (p.bias) v += p.bias[col];
     if (p.act == 1) v = leaky(v);
+    else if (p.act == 2) v = fmaxf(v, 0.f);
     ((float*)p.out)[(long)row * p.ldc + col] = v;
   } else if (EPI == EPI_PATCH) {
     int b = row / p.P, pi = row - b * p.P;

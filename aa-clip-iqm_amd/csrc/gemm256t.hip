@@ -161,6 +161,9 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           if (p.act == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = leaky(v[j]);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
           }
         } else if (EPI == EPI_PATCH) {
           v = v + extra[it];

@@ -1,0 +1,301 @@
+// Kernels of the IQM side branch (reference model/iqm.py + the glue of model/adapter.py:186-269 and the maps of
+// test_last.py:102-147).  The branch is 2 QUERIES per image attending to 4 x 1369 projected patch
+// rows and to the anchors: its matrix products (patch-row projections, key/value projections: ~45 GFLOP per image)
+// run on the library's MFMA GEMM; what is left is tiny and HBM- or latency-bound, one wavefront-level kernel each:
+//   small_attention      softmax(q k^T / sqrt(d)) v for <= 4 queries per (image, head) over Lk keys
+//   residual_layernorm   LayerNorm(a + b)                 (IQM_SelfOutput / IQM_Output, iqm.py:143-154,219-230)
+//   combine3             wa a + wb b + wc c               (the fixed 0.4 / 0.3 / 0.3 fusion of iqm.py:311-315)
+//   linear_smallk        y = x W^T + b for in_features <= 4 (the anchors arrive as [B, 768, 2]: "768 tokens of width
+//                        2", adapter.py:229-246)
+//   drop_cls_rows        [B, L, E] -> rows 1.. of every image written at a row offset of [B, NLP, E] (torch.cat of
+//                        the projected tap levels, adapter.py:206-211)
+//   iqm_scores / iqm_upsample   sigmoid(cos(f, q_abnormal) - cos(f, q_normal)) per patch, bilinear
+//                        (align_corners=False) upsampling, level sum and the 0.6 / 0.4 fusion with the text map
+#include "common.h"
+#include "kernels.h"
+
+namespace aaclip {
+
+template <typename T> AACLIP_DEV float ldf(const T* p) { return (float)*p; }
+
+// ---- small_attention: grid (H, B), 256 threads.  q [B, nq, H*hd] fp32 (nq <= 4); k, v [B*Lk, H*hd] of T;
+// out [B, nq, H*hd] fp32.  Pass 1: one key per thread and step, scores to LDS (Lk <= 8192), block max / sum.
+// Pass 2: thread = (4-column chunk, key slice), partial sums reduced through LDS.
+constexpr int SA_MAXQ = 4, SA_MAXK = 8192, SA_MAXHD = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void small_attention_kernel(const float* __restrict__ q, const T* __restrict__ k,
+                                                              const T* __restrict__ v, float* __restrict__ out, int nq,
+                                                              int Lk, int H, int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [nq][Lk] scores, then reduction scratch
+  __shared__ float qs[SA_MAXQ][SA_MAXHD];
+  __shared__ float red[SA_MAXQ][256];
+  __shared__ float stat[SA_MAXQ][2];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int D = H * hd;
+  for (int i = tid; i < nq * hd; i += 256) qs[i / hd][i % hd] = q[((long)b * nq + i / hd) * D + h * hd + i % hd] * scale;
+  __syncthreads();
+  float mx[SA_MAXQ];
+#pragma unroll
+  for (int a = 0; a < SA_MAXQ; ++a) mx[a] = -INFINITY;
+  for (int j = tid; j < Lk; j += 256) {
+    const T* kr = k + ((long)b * Lk + j) * D + h * hd;
+    float s[SA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < hd; d += 4) {
+      const float k0 = ldf(kr + d), k1 = ldf(kr + d + 1), k2 = ldf(kr + d + 2), k3 = ldf(kr + d + 3);
+#pragma unroll
+      for (int a = 0; a < SA_MAXQ; ++a)
+        if (a < nq) s[a] = fmaf(k3, qs[a][d + 3], fmaf(k2, qs[a][d + 2], fmaf(k1, qs[a][d + 1], fmaf(k0, qs[a][d], s[a]))));
+    }
+#pragma unroll
+    for (int a = 0; a < SA_MAXQ; ++a)
+      if (a < nq) { sm[a * Lk + j] = s[a]; mx[a] = fmaxf(mx[a], s[a]); }
+  }
+#pragma unroll
+  for (int a = 0; a < SA_MAXQ; ++a) red[a][tid] = mx[a];
+  __syncthreads();
+  if (tid < nq) {
+    float m = -INFINITY;
+    for (int i = 0; i < 256; ++i) m = fmaxf(m, red[tid][i]);
+    stat[tid][0] = m;
+  }
+  __syncthreads();
+  float sum[SA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = tid; j < Lk; j += 256)
+#pragma unroll
+    for (int a = 0; a < SA_MAXQ; ++a)
+      if (a < nq) { const float p = expf(sm[a * Lk + j] - stat[a][0]); sm[a * Lk + j] = p; sum[a] += p; }
+#pragma unroll
+  for (int a = 0; a < SA_MAXQ; ++a) red[a][tid] = sum[a];
+  __syncthreads();
+  if (tid < nq) {
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += red[tid][i];   // fixed order: deterministic
+    stat[tid][1] = 1.0f / t;
+  }
+  __syncthreads();
+  // pass 2
+  const int nch = hd / 4;                 // 4-column chunks (hd % 4 == 0)
+  const int slices = 256 / nch;           // key slices
+  const int c = tid % nch, sl = tid / nch;
+  float acc[SA_MAXQ][4];
+#pragma unroll
+  for (int a = 0; a < SA_MAXQ; ++a) acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0.f;
+  if (sl < slices) {
+    for (int j = sl; j < Lk; j += slices) {
+      const T* vr = v + ((long)b * Lk + j) * D + h * hd + c * 4;
+      const float v0 = ldf(vr), v1 = ldf(vr + 1), v2 = ldf(vr + 2), v3 = ldf(vr + 3);
+#pragma unroll
+      for (int a = 0; a < SA_MAXQ; ++a)
+        if (a < nq) {
+          const float p = sm[a * Lk + j];
+          acc[a][0] = fmaf(p, v0, acc[a][0]); acc[a][1] = fmaf(p, v1, acc[a][1]);
+          acc[a][2] = fmaf(p, v2, acc[a][2]); acc[a][3] = fmaf(p, v3, acc[a][3]);
+        }
+    }
+  }
+  __syncthreads();                        // everyone is done reading the probabilities: reuse sm as [slices][nq][hd]
+  if (sl < slices)
+#pragma unroll
+    for (int a = 0; a < SA_MAXQ; ++a)
+      if (a < nq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm[(sl * nq + a) * hd + c * 4 + e] = acc[a][e];
+  __syncthreads();
+  for (int i = tid; i < nq * hd; i += 256) {
+    const int a = i / hd, d = i % hd;
+    float t = 0.f;
+    for (int s2 = 0; s2 < slices; ++s2) t += sm[(s2 * nq + a) * hd + d];
+    out[((long)b * nq + a) * D + h * hd + d] = t * stat[a][1];
+  }
+}
+
+const char* small_attention_check(int nq, int Lk, int H, int hd) {
+  if (nq < 1 || nq > SA_MAXQ) return "small_attention: 1..4 queries per image";
+  if (Lk < 1 || Lk > SA_MAXK) return "small_attention: 1..8192 keys";
+  if (H < 1 || hd < 4 || hd > SA_MAXHD || hd % 4) return "small_attention: head size must be a multiple of 4, <= 128";
+  if ((256 / (hd / 4)) < 1) return "small_attention: head size too large";
+  return nullptr;
+}
+
+void launch_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
+                            int H, int hd, float scale, hipStream_t s) {
+  const int slices = 256 / (hd / 4);
+  size_t a = (size_t)nq * Lk, b2 = (size_t)slices * nq * hd;
+  const size_t shm = (a > b2 ? a : b2) * sizeof(float);
+  dim3 g(H, B);
+  if (kv_dtype == AACLIP_F16)
+    hipLaunchKernelGGL(small_attention_kernel<f16>, g, dim3(256), shm, s, q, (const f16*)k, (const f16*)v, out, nq, Lk, H, hd, scale);
+  else if (kv_dtype == AACLIP_BF16)
+    hipLaunchKernelGGL(small_attention_kernel<bf16>, g, dim3(256), shm, s, q, (const bf16*)k, (const bf16*)v, out, nq, Lk, H, hd, scale);
+  else
+    hipLaunchKernelGGL(small_attention_kernel<float>, g, dim3(256), shm, s, q, (const float*)k, (const float*)v, out, nq, Lk, H, hd, scale);
+}
+
+// ---- residual_layernorm: out = LayerNorm(a + b) over D (multiple of 64, <= 4096), one wave per row, fp32
+__global__ __launch_bounds__(256) void residual_layernorm_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, long rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pa = a + row * D;
+  const float* pb = b ? b + row * D : nullptr;
+  float sum = 0.f;
+  for (int i = lane; i < D; i += 64) sum += pa[i] + (pb ? pb[i] : 0.f);
+  const float mean = wave_sum(sum) / (float)D;
+  float var = 0.f;
+  for (int i = lane; i < D; i += 64) { const float x = pa[i] + (pb ? pb[i] : 0.f) - mean; var = fmaf(x, x, var); }
+  const float rstd = rsqrtf(wave_sum(var) / (float)D + eps);
+  for (int i = lane; i < D; i += 64) out[row * D + i] = (pa[i] + (pb ? pb[i] : 0.f) - mean) * rstd * w[i] + bias[i];
+}
+void launch_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,
+                               int D, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, b, w, bias, out, rows, D, eps);
+}
+
+// ---- combine3
+__global__ __launch_bounds__(256) void combine3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ c, float wa, float wb, float wc,
+                                                       float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = wa * a[i] + wb * (b ? b[i] : 0.f) + wc * (c ? c[i] : 0.f);
+}
+void launch_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, long n,
+                     hipStream_t s) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(combine3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, c, wa, wb, wc, out, n);
+}
+
+// ---- linear_smallk: y[r, n] = sum_{k < K} x[r, k] W[n, k] + bias[n], K <= 4; x fp32 [R, K]; y [R, N] of T
+template <typename T>
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, T* __restrict__ y, long R,
+                                                            int N, int K) {
+  const long total = R * N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / N;
+    const int n = (int)(i - r * N);
+    float acc = bias ? bias[n] : 0.f;
+    for (int kk = 0; kk < K; ++kk) acc = fmaf(x[r * K + kk], W[n * K + kk], acc);
+    y[i] = (T)acc;
+  }
+}
+void launch_linear_smallk(int out_dtype, const float* x, const float* W, const float* bias, void* y, long R, int N, int K,
+                          hipStream_t s) {
+  long blocks = (R * N + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  dim3 g((unsigned)blocks);
+  if (out_dtype == AACLIP_F16) hipLaunchKernelGGL(linear_smallk_kernel<f16>, g, dim3(256), 0, s, x, W, bias, (f16*)y, R, N, K);
+  else if (out_dtype == AACLIP_BF16) hipLaunchKernelGGL(linear_smallk_kernel<bf16>, g, dim3(256), 0, s, x, W, bias, (bf16*)y, R, N, K);
+  else hipLaunchKernelGGL(linear_smallk_kernel<float>, g, dim3(256), 0, s, x, W, bias, (float*)y, R, N, K);
+}
+
+// ---- drop_cls_rows: src [B, L, E] of T -> dst rows [b][row_off + t - 1], t = 1..L-1, of [B, rows_per_image, E]
+template <typename T>
+__global__ __launch_bounds__(256) void drop_cls_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int L,
+                                                            int E, int rows_per_image, int row_off) {
+  const int e8 = E / 8;                        // 16-byte units for 16-bit T, 32-byte for fp32 (two loads)
+  const long total = (long)B * (L - 1) * e8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / e8;
+    const int c = (int)(i - r * e8) * 8;
+    const long b = r / (L - 1), t = r - b * (L - 1);
+    const T* s = src + ((b * L) + 1 + t) * E + c;
+    T* d = dst + ((b * rows_per_image) + row_off + t) * E + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = s[j];
+  }
+}
+void launch_drop_cls_rows(int dtype, const void* src, void* dst, int B, int L, int E, int rows_per_image, int row_off,
+                          hipStream_t s) {
+  long blocks = ((long)B * (L - 1) * (E / 8) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  dim3 g((unsigned)blocks);
+  if (dtype == AACLIP_F16) hipLaunchKernelGGL(drop_cls_rows_kernel<f16>, g, dim3(256), 0, s, (const f16*)src, (f16*)dst, B, L, E, rows_per_image, row_off);
+  else if (dtype == AACLIP_BF16) hipLaunchKernelGGL(drop_cls_rows_kernel<bf16>, g, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, B, L, E, rows_per_image, row_off);
+  else hipLaunchKernelGGL(drop_cls_rows_kernel<float>, g, dim3(256), 0, s, (const float*)src, (float*)dst, B, L, E, rows_per_image, row_off);
+}
+
+// ---- IQM maps.  iqm_scores: one wave per patch row: sigmoid(cos(f, q1) - cos(f, q0)) with F.cosine_similarity's
+// eps (1e-8 on the product of norms).  seg [B, P, E] fp32, queries [B, 2, E] fp32 -> grid [B, P]
+template <int NCH>
+__global__ __launch_bounds__(256) void iqm_scores_kernel(const float* __restrict__ seg, const float* __restrict__ qv,
+                                                         float* __restrict__ out, int B, int P) {
+  constexpr int E = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * P) return;
+  const long b = row / P;
+  const float* f = seg + row * E;
+  const float* q0 = qv + b * 2 * E;
+  const float* q1 = q0 + E;
+  float ff = 0.f, d0 = 0.f, d1 = 0.f, n0 = 0.f, n1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e0 = (c * 64 + lane) * 4;
+    const f32x4 fv = *(const f32x4*)(f + e0), a = *(const f32x4*)(q0 + e0), bb = *(const f32x4*)(q1 + e0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ff = fmaf(fv[j], fv[j], ff);
+      d0 = fmaf(fv[j], a[j], d0); n0 = fmaf(a[j], a[j], n0);
+      d1 = fmaf(fv[j], bb[j], d1); n1 = fmaf(bb[j], bb[j], n1);
+    }
+  }
+  ff = wave_sum(ff); d0 = wave_sum(d0); d1 = wave_sum(d1); n0 = wave_sum(n0); n1 = wave_sum(n1);
+  if (lane == 0) {
+    // torch: x.y / max(|x| |y|, eps) computed as x.y / sqrt(clamp(|x|^2 |y|^2, eps^2))
+    const float c0 = d0 / sqrtf(fmaxf(ff * n0, 1e-16f)), c1 = d1 / sqrtf(fmaxf(ff * n1, 1e-16f));
+    out[row] = 1.0f / (1.0f + expf(-(c1 - c0)));
+  }
+}
+void launch_iqm_scores(const float* seg, const float* q, float* grid, int B, int P, int E, hipStream_t s) {
+  dim3 g((unsigned)(((long)B * P + 3) / 4));
+  switch (E / 256) {
+    case 1: hipLaunchKernelGGL(iqm_scores_kernel<1>, g, dim3(256), 0, s, seg, q, grid, B, P); break;
+    case 2: hipLaunchKernelGGL(iqm_scores_kernel<2>, g, dim3(256), 0, s, seg, q, grid, B, P); break;
+    case 3: hipLaunchKernelGGL(iqm_scores_kernel<3>, g, dim3(256), 0, s, seg, q, grid, B, P); break;
+    case 4: hipLaunchKernelGGL(iqm_scores_kernel<4>, g, dim3(256), 0, s, seg, q, grid, B, P); break;
+  }
+}
+
+// grids [NL][B, g, g] -> out [B, S, S] = w_base * base + w_iqm * sum_l bilinear_{align_corners=False}(grid_l)
+constexpr int IQ_MAXG = 40;
+__global__ __launch_bounds__(256) void iqm_upsample_kernel(const float* __restrict__ grids, const float* __restrict__ base,
+                                                           float* __restrict__ out, int B, int g, int S, int NL,
+                                                           float w_base, float w_iqm, int rows_per_band) {
+  __shared__ float m[4][IQ_MAXG * IQ_MAXG];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int l = 0; l < NL; ++l)
+    for (int i = tid; i < g * g; i += 256) m[l][i] = grids[((long)l * B + b) * g * g + i];
+  __syncthreads();
+  const float scale = (float)g / (float)S;
+  const int y_begin = blockIdx.x * rows_per_band;
+  int y_end = y_begin + rows_per_band;
+  if (y_end > S) y_end = S;
+  for (long i = (long)y_begin * S + tid; i < (long)y_end * S; i += 256) {
+    const int y = i / S, x = i - (long)y * S;
+    float sy = scale * ((float)y + 0.5f) - 0.5f, sx = scale * ((float)x + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
+    const float ly1 = sy - y0, ly0 = 1.0f - ly1, lx1 = sx - x0, lx0 = 1.0f - lx1;
+    float acc = 0.f;
+    for (int l = 0; l < NL; ++l) {
+      const float* p = m[l];
+      const float v = ly0 * (lx0 * p[y0 * g + x0] + lx1 * p[y0 * g + x1]) + ly1 * (lx0 * p[y1 * g + x0] + lx1 * p[y1 * g + x1]);
+      acc = (l == 0) ? v : acc + v;
+    }
+    const long o = (long)b * S * S + i;
+    out[o] = base ? w_base * base[o] + w_iqm * acc : w_iqm * acc;
+  }
+}
+void launch_iqm_upsample(const float* grids, const float* base, float* out, int B, int g, int S, int NL, float w_base,
+                         float w_iqm, hipStream_t s) {
+  const int bands = 14;
+  const int rpb = (S + bands - 1) / bands;
+  hipLaunchKernelGGL(iqm_upsample_kernel, dim3(bands, B), dim3(256), 0, s, grids, base, out, B, g, S, NL, w_base, w_iqm, rpb);
+}
+
+}  // namespace aaclip

@@ -96,6 +96,22 @@ bool gemm_routes_to_256t(int dtype, const GemmParams& p);   // launch_gemm will 
 void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s);
 void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s);
 
+// ---- iqm.hip : the IQM side branch's small kernels (include/aaclip.h, "IQM side branch")
+const char* small_attention_check(int nq, int Lk, int H, int hd);
+void launch_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
+                            int H, int hd, float scale, hipStream_t s);
+void launch_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,
+                               int D, float eps, hipStream_t s);
+void launch_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, long n,
+                     hipStream_t s);
+void launch_linear_smallk(int out_dtype, const float* x, const float* W, const float* bias, void* y, long R, int N, int K,
+                          hipStream_t s);
+void launch_drop_cls_rows(int dtype, const void* src, void* dst, int B, int L, int E, int rows_per_image, int row_off,
+                          hipStream_t s);
+void launch_iqm_scores(const float* seg, const float* q, float* grid, int B, int P, int E, hipStream_t s);
+void launch_iqm_upsample(const float* grids, const float* base, float* out, int B, int g, int S, int NL, float w_base,
+                         float w_iqm, hipStream_t s);
+
 // ---- preprocess.hip : 8-bit bicubic resize + ToTensor + Normalize (Pillow-exact)
 int resample_ksize(int in_size, int out_size);
 void resample_table(int in_size, int out_size, int32_t* bounds, int32_t* coefs);   // host buffers

@@ -1,11 +1,13 @@
 """AdaptedCLIP on the MI355X HIP path: frozen CLIP towers + residual adapters +
 4-level patch taps + seg/det projections (reference model/adapter.py:10-304).
 
-Scope: the visual forward (adapter.py:137-184) and the
-adapted text encoder (:273-304) are built.  The IQM side branch (:186-269) is
-not: its weights are never checkpointed by the reference and it is outside the
-north-star path, so forward() always returns None for iqm_outputs, exactly what
-the reference returns when text_embeddings is None.
+Scope: the visual forward (adapter.py:137-184), the adapted
+text encoder (:273-304) and the IQM side branch (:186-269, model/iqm.py): like the
+reference, forward() runs the branch when text_embeddings is given and returns
+None for iqm_outputs otherwise.  The reference never checkpoints the branch and
+creates two of its layers with fresh random weights inside forward; here all of
+its parameters are ordinary, seeded at construction and part of state_dict()
+(model/iqm.py explains the two differences).
 """
 from __future__ import annotations
 
@@ -16,7 +18,10 @@ from torch import nn
 
 from aaclip_hip import engine
 
+from aaclip_hip._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, EPI_ACT_F32, EPI_BIAS
+
 from .adapter_modules import SimpleAdapter, SimpleProj
+from .iqm import IQM, IQMOutput, sinusoidal_positions
 from .transformer import set_precision
 
 
@@ -48,7 +53,25 @@ class AdaptedCLIP(nn.Module):
             for p in mod.parameters():
                 if p.dim() > 1:
                     nn.init.xavier_uniform_(p)          # reference adapter.py:107-113
-        self.iqm = None                                  # out of scope, see module docstring
+        # ---- IQM side branch, reference adapter.py:56-92 (parameter names kept)
+        h = iqm_hidden_size
+        self.iqm_hidden_size = h
+        self.iqm = IQM(hidden_size=h, num_hidden_layers=iqm_num_layers, num_attention_heads=iqm_num_heads,
+                       encoder_hidden_size=h, text_encoder_hidden_size=768)
+        self.class_query_mlp = nn.Sequential(nn.Linear(dv, h), nn.ReLU(), nn.Linear(h, h))
+        self.query_adapters = nn.ModuleList([SimpleProj(dv, h, relu) for _ in range(len(levels))])
+        self.visual_feature_proj = nn.Linear(h, h)       # the reference creates these two lazily, with random
+        self.text_feature_proj = nn.Linear(2, 768)       # weights, inside forward (adapter.py:213-218,241-243)
+        self.pos_embedding = nn.Parameter(sinusoidal_positions(512, h))
+        self.visual_weight = nn.Parameter(torch.tensor(0.6))    # computed and unused by the reference too (:248-255)
+        self.text_weight = nn.Parameter(torch.tensor(0.4))
+        self.iqm_dropout = nn.Identity()
+        self.iqm_layer_norm = nn.LayerNorm(h)
+        for mod in (self.iqm, self.class_query_mlp, self.query_adapters):
+            for p in mod.parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)          # reference adapter.py:114-123
+        self._zero_bias = {}
         set_precision(self, getattr(clip_model, "precision", "fp32"))
 
     def _code(self) -> int:
@@ -77,6 +100,10 @@ class AdaptedCLIP(nn.Module):
         det_token = None
         n_levels = len(self.levels)
         blocks = list(v.transformer.resblocks)
+        iqm_on = text_embeddings is not None
+        dt = engine.torch_dtype(code)
+        P = L - 1
+        vis_cat = torch.empty(B, n_levels * P, self.iqm_hidden_size, dtype=dt, device=xs.device) if iqm_on else None
         run, run_aw = [], []   # consecutive blocks up to the next tap: one aaclip_blocks call
         for i, blk in enumerate(blocks):
             run.append(blk)
@@ -93,7 +120,63 @@ class AdaptedCLIP(nn.Module):
                 seg_tokens.append(seg)
                 if last:
                     det_token = det
-        return seg_tokens, det_token, None
+                if iqm_on:
+                    self._iqm_project_level(xs, k, vis_cat, B, L, code)
+        if not iqm_on:
+            return seg_tokens, det_token, None
+        return seg_tokens, det_token, self._iqm_branch(xs, vis_cat, text_embeddings, B, L, code)
+
+    # -- reference model/adapter.py:205-208: query_adapters[k](ln_post(tap k)) for the patch rows, written into the
+    #    slice of the concatenated visual features (torch.cat over dim 1, :210-211) that level k owns
+    def _iqm_project_level(self, xs, k, vis_cat, B, L, code):
+        v = self.image_encoder
+        dt = engine.torch_dtype(code)
+        h = self.iqm_hidden_size
+        ln = engine.layernorm(xs, v.ln_post.weight, v.ln_post.bias, out_code=code)          # [B*L, D] compute dtype
+        w = engine.CACHE.get(self.query_adapters[k].weight, code)
+        if self.relu:
+            tmp = torch.empty(B * L, h, dtype=torch.float32, device=xs.device)
+            engine.gemm(code, EPI_ACT_F32, ln, w, None, tmp, act=ACT_LEAKY)
+            tmp = tmp.to(dt)
+        else:
+            zb = self._zero_bias.get(xs.device)
+            if zb is None or zb.numel() < h:
+                zb = self._zero_bias[xs.device] = torch.zeros(h, dtype=torch.float32, device=xs.device)
+            tmp = torch.empty(B * L, h, dtype=dt, device=xs.device)
+            engine.gemm(code, EPI_BIAS, ln, w, zb, tmp)
+        engine.drop_cls_rows(tmp, vis_cat, B, L, k * (L - 1), code)
+
+    # -- reference model/adapter.py:186-269
+    def _iqm_branch(self, xs, vis_cat, text_embeddings, B, L, code):
+        dt = engine.torch_dtype(code)
+        h = self.iqm_hidden_size
+        dev = xs.device
+        te = text_embeddings.to(dev)
+        if te.dim() != 3 or te.shape[0] != B or te.shape[-1] != 2:
+            raise NotImplementedError(
+                "the IQM branch is built for text_embeddings of shape [B, 768, 2] (what test_last.py:84 and train.py "
+                "pass): the reference would re-create text_feature_proj with another in_features for any other form")
+        # 1. queries: class_query_mlp(CLS row) for both, plus the first two sinusoidal positions (:191-203)
+        cls = xs.view(B, L, -1)[:, 0, :].to(dt).contiguous()
+        m0, m2 = self.class_query_mlp[0], self.class_query_mlp[2]
+        t1 = torch.empty(B, h, dtype=torch.float32, device=dev)
+        engine.gemm(code, EPI_ACT_F32, cls, engine.CACHE.get(m0.weight, code), engine._f32c(m0.bias), t1, act=ACT_RELU)
+        cq = torch.empty(B, h, dtype=torch.float32, device=dev)
+        engine.gemm(code, EPI_ACT_F32, t1.to(dt), engine.CACHE.get(m2.weight, code), engine._f32c(m2.bias), cq)
+        pos = engine._f32c(self.pos_embedding)[:, :2, :].expand(B, 2, h).contiguous()
+        query = engine.combine3(cq.unsqueeze(1).expand(B, 2, h).contiguous(), pos, None, 1.0, 1.0, 0.0)
+        # 2. patch rows of all levels -> query space (:210-221)
+        vp = self.visual_feature_proj
+        vis = torch.empty(vis_cat.shape[0] * vis_cat.shape[1], h, dtype=dt, device=dev)
+        engine.gemm(code, EPI_BIAS, vis_cat.view(-1, h), engine.CACHE.get(vp.weight, code), engine._f32c(vp.bias), vis)
+        # 3. anchors [B, 768, 2] read as 768 tokens of width 2 -> Linear(2, 768) (:229-246)
+        tp = self.text_feature_proj
+        txt = engine.linear_smallk(te, tp.weight, tp.bias, code)
+        out = self.iqm(query_embeds=query, query_length=2, encoder_hidden_states=vis.view(B, -1, h),
+                       text_encoder_hidden_states=txt.view(B, te.shape[1], tp.weight.shape[0]), code=code)
+        hfin = engine.residual_layernorm(out.last_hidden_state.reshape(B * 2, h), None, self.iqm_layer_norm,
+                                         self.iqm_layer_norm.eps)                             # :265-266
+        return IQMOutput(hfin.view(B, 2, h))
 
     # -- reference model/adapter.py:273-304
     def encode_text(self, text, adapt_text=True):

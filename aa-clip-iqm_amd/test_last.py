@@ -6,7 +6,9 @@ Differences from the reference, all on purpose:
   * the four per-level maps and their sum come from ONE fused kernel (calculate_anomaly_map);
   * the image score is the intended (det_b . t_abnormal + 1)/2 (the reference's broadcast
     quirk is documented in DESIGN.md);
-  * the IQM branch is not built, so maps are the text-only branch (test_last.py:148-149);
+  * the IQM branch runs like in the reference (maps = 0.6 * text + 0.4 * IQM, test_last.py:67-68,102-147) but with
+    weights that exist: `iqm_branch.pth` in save_path if present, else the seeded initialisation of AdaptedCLIP
+    (the reference evaluates it with never-saved random weights); `--iqm off` gives the text-only branch (:148-149);
   * checkpoints are read with weights_only=True;
   * `--device_preprocess` moves resize + normalise onto the GPU (bit-identical to the CPU transform).
 """
@@ -39,10 +41,14 @@ def setup_seed(seed: int) -> None:
     random.seed(seed)
 
 
+IQM_WEIGHT, TEXT_WEIGHT = 0.4, 0.6     # reference test_last.py:67-68
+
+
 def get_predictions(model, class_text_embeddings: torch.Tensor, test_loader, device, img_size: int,
-                    dataset: str = "MVTec"):
+                    dataset: str = "MVTec", use_iqm: bool = True):
     """-> (masks [N,1,S,S], labels [N], preds [N,S,S], preds_image [N], file_names) like
-    reference test_last.py:53-158 (text-only branch)."""
+    reference test_last.py:53-158: text anomaly map summed over the tap levels, and -- when the IQM branch runs --
+    0.6 * that + 0.4 * the IQM map (:102-147), both from fused kernels."""
     masks, labels, preds, preds_image, file_names = [], [], [], [], []
     domain = DOMAINS[dataset]
     for input_data in test_loader:
@@ -54,15 +60,21 @@ def get_predictions(model, class_text_embeddings: torch.Tensor, test_loader, dev
         file_names.extend(input_data["file_name"])
         if image.dtype == torch.uint8:                       # raw HWC frames: resize + normalise on the GPU
             image = engine.preprocess(image, img_size)
-        patch_features, det_feature, _ = model(image, text_embeddings=None)
+        epoch_text_feature = class_text_embeddings.unsqueeze(0).repeat(image.size(0), 1, 1) if use_iqm else None
+        patch_features, det_feature, iqm_outputs = model(image, text_embeddings=epoch_text_feature)
         preds_image.append(image_score(det_feature, class_text_embeddings).cpu().numpy())
-        preds.append(calculate_anomaly_map(patch_features, class_text_embeddings, img_size, domain=domain).cpu().numpy())
+        final_map = calculate_anomaly_map(patch_features, class_text_embeddings, img_size, domain=domain)
+        if iqm_outputs is not None:
+            final_map = engine.iqm_map(patch_features, iqm_outputs.last_hidden_state, img_size, base=final_map,
+                                       w_base=TEXT_WEIGHT, w_iqm=IQM_WEIGHT)
+        preds.append(final_map.cpu().numpy())
     return (np.concatenate(masks, axis=0), np.concatenate(labels, axis=0), np.concatenate(preds, axis=0),
             np.concatenate(preds_image, axis=0), file_names)
 
 
 def evaluate(model, image_datasets: Dict[str, torch.utils.data.Dataset], text_embeddings: Dict[str, torch.Tensor],
-             device, img_size: int, dataset: str, batch_size: int = 32, loader_kwargs=None, logger=None) -> List[dict]:
+             device, img_size: int, dataset: str, batch_size: int = 32, loader_kwargs=None, logger=None,
+             use_iqm: bool = True) -> List[dict]:
     """The per-class loop of reference test_last.py:282-326; returns the result rows, last row = Average."""
     rows = []
     for class_name, image_dataset in image_datasets.items():
@@ -70,7 +82,7 @@ def evaluate(model, image_datasets: Dict[str, torch.utils.data.Dataset], text_em
         with torch.no_grad():
             masks, labels, preds, preds_image, _ = get_predictions(
                 model=model, class_text_embeddings=text_embeddings[class_name], test_loader=loader, device=device,
-                img_size=img_size, dataset=dataset)
+                img_size=img_size, dataset=dataset, use_iqm=use_iqm)
         rows.append(metrics_eval(masks, labels, preds, preds_image, class_name, domain=DOMAINS[dataset]))
         if logger:
             logger.info("%s", rows[-1])
@@ -102,6 +114,13 @@ def load_adapters(model: AdaptedCLIP, save_path: str, logger=None) -> bool:
     model.image_adapter.load_state_dict(ckpt["image_adapter"])
     if logger:
         logger.info("load model from epoch %s", ckpt.get("epoch"))
+    iqm_file = os.path.join(save_path, "iqm_branch.pth")
+    if os.path.exists(iqm_file):      # everything the IQM branch owns (AdaptedCLIP.state_dict() keys outside the towers/adapters)
+        sd = torch.load(iqm_file, map_location="cpu", weights_only=True)
+        missing, unexpected = model.load_state_dict(sd.get("iqm_branch", sd), strict=False)
+        assert not unexpected, unexpected
+        if logger:
+            logger.info("IQM branch weights loaded from %s", iqm_file)
     return adapt_text
 
 
@@ -122,6 +141,8 @@ def main(argv=None):
     parser.add_argument("--image_adapt_until", type=int, default=6)
     parser.add_argument("--precision", type=str, default="fp16", help="fp32 (exact), fp16 or bf16 matrix products")
     parser.add_argument("--device_preprocess", action="store_true", help="resize + normalise on the GPU")
+    parser.add_argument("--iqm", choices=["on", "off"], default="on",
+                        help="on: maps = 0.6 text + 0.4 IQM like the reference; off: text-only branch")
     args = parser.parse_args(argv)
 
     setup_seed(args.seed)
@@ -146,7 +167,7 @@ def main(argv=None):
         text_embeddings = get_adapted_text_embedding(model if adapt_text else clip_model, args.dataset, device)
     rows = evaluate(model, image_datasets, text_embeddings, device, args.img_size, args.dataset,
                     batch_size=args.image_batch_size, loader_kwargs={"num_workers": 4, "pin_memory": True},
-                    logger=logger)
+                    logger=logger, use_iqm=args.iqm == "on")
     table = format_table(rows)
     logger.info("final results:\n%s", table)
     print(table)

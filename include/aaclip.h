@@ -33,7 +33,7 @@ extern "C" {
 #define AACLIP_ABI_VERSION 3
 
 enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2 };
-enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1 };
+enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1, AACLIP_ACT_RELU = 2 };
 /* generic GEMM epilogues (aaclip_gemm) */
 enum { AACLIP_EPI_BIAS = 0, AACLIP_EPI_BIAS_GELU = 1, AACLIP_EPI_BIAS_RESID = 2, AACLIP_EPI_ACT_F32 = 3 };
 
@@ -212,6 +212,41 @@ int aaclip_gemm(int dtype, int epi, const void* A, long lda, const void* W, cons
                 int M, int N, int K, int act, int scale_cols, float scale, void* stream);
 int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream);
 int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight, void* stream);
+
+/* ---- IQM side branch (reference model/iqm.py, the glue of model/adapter.py:186-269 and the IQM maps of
+ * test_last.py:102-147).  Its matrix products -- class_query_mlp, query_adapters,
+ * visual_feature_proj, every query / key / value / dense / intermediate Linear of IQMLayer -- go through aaclip_gemm
+ * (AACLIP_EPI_BIAS for 16-bit key / value / patch operands, AACLIP_EPI_BIAS_GELU for intermediate_query,
+ * AACLIP_EPI_ACT_F32 with a bias for the 2-row query side).  The entry points below are what is left. */
+
+/* softmax(q k^T * scale) v per (image, head) for nq <= 4 queries over Lk <= 8192 keys: the core of
+ * IQM_MultiHeadAttention.forward (reference model/iqm.py:108-139; masks are all-zero on this path, dropout is the
+ * identity in eval).  q, out [B, nq, H*hd] fp32; k, v [B*Lk, H*hd] in kv_dtype; hd a multiple of 4, <= 128. */
+int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
+                           int H, int hd, float scale, void* stream);
+/* out = LayerNorm(a + b) over the last dimension D (b may be NULL): IQM_SelfOutput / IQM_Output (reference
+ * model/iqm.py:143-154,219-230, eps 1e-12), IQM.layernorm (:617) and iqm_layer_norm (model/adapter.py:265, eps 1e-5). */
+int aaclip_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,
+                              int D, float eps, void* stream);
+/* out = wa a + wb b + wc c (b, c may be NULL): the fixed 0.4 / 0.3 / 0.3 fusion of reference model/iqm.py:311-315 and
+ * the query + positional embedding sum of model/adapter.py:199-203. */
+int aaclip_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, long n,
+                    void* stream);
+/* y = x W^T + bias for in_features K <= 4: text_feature_proj, which the reference creates as Linear(2, 768) because
+ * the anchors reach the branch as [B, 768, 2] (model/adapter.py:229-246).  x fp32 [R, K], W fp32 [N, K], y [R, N] in
+ * out_dtype. */
+int aaclip_linear_smallk(int out_dtype, const float* x, const float* W, const float* bias, void* y, long R, int N, int K,
+                         void* stream);
+/* Rows 1..L-1 of every image of src [B, L, E] (dtype) -> rows row_off.. of every image of dst [B, rows_per_image, E]:
+ * the torch.cat over dim 1 of the projected tap levels without their CLS row (model/adapter.py:171,206-211). */
+int aaclip_drop_cls_rows(int dtype, const void* src, void* dst, int B, int L, int E, int rows_per_image, int row_off,
+                         void* stream);
+/* IQM anomaly map, reference test_last.py:102-147: per level sigmoid(cos(f, q_abnormal) - cos(f, q_normal)) on the
+ * patch grid, bilinear (align_corners=False) to S x S, summed over NL <= 4 levels; out = w_base * base + w_iqm * that
+ * (base = the text anomaly map, 0.6 / 0.4 in test_last.py:67-68,141-147; base NULL = IQM map alone).
+ * seg[l] [B, g*g, E] fp32, queries [B, 2, E] fp32 (row 0 normal, row 1 abnormal), ws >= NL*B*g*g floats. */
+int aaclip_iqm_map(const float* const* seg, int NL, const float* queries, const float* base, float* out, int B, int g,
+                   int E, int S, float w_base, float w_iqm, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -205,6 +205,93 @@ def adapted_visual_forward(img: torch.Tensor, sd: SD, ia: SD, heads: int,
 
 
 # --------------------------------------------------------------------------
+# IQM side branch
+# --------------------------------------------------------------------------
+def _iqm_linear(x: torch.Tensor, sd: SD, name: str) -> torch.Tensor:
+    y = x @ sd[name + ".weight"].t()
+    return y + sd[name + ".bias"] if (name + ".bias") in sd else y
+
+
+def _iqm_attention(h: torch.Tensor, enc: Optional[torch.Tensor], sd: SD, p: str, heads: int) -> torch.Tensor:
+    """IQM_Attention = IQM_MultiHeadAttention + IQM_SelfOutput, reference model/iqm.py:23-139,143-154,157-204:
+    q from the hidden states, k/v from `enc` (cross) or from the hidden states (self); scores / sqrt(head size)
+    (:116), masks are all-zero on this path (:621-642), dropout is the identity in eval; then
+    LayerNorm(dense(context) + hidden_states) with eps 1e-12."""
+    B, nq, D = h.shape
+    src = h if enc is None else enc
+    hd = D // heads
+    q = _iqm_linear(h, sd, p + "attention.query").view(B, nq, heads, hd).transpose(1, 2)
+    k = _iqm_linear(src, sd, p + "attention.key").view(B, src.shape[1], heads, hd).transpose(1, 2)
+    v = _iqm_linear(src, sd, p + "attention.value").view(B, src.shape[1], heads, hd).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+    ctx = (a @ v).transpose(1, 2).reshape(B, nq, D)
+    return layer_norm(_iqm_linear(ctx, sd, p + "output.dense") + h, sd[p + "output.LayerNorm.weight"],
+                      sd[p + "output.LayerNorm.bias"], 1e-12)
+
+
+def iqm_branch(x_final: torch.Tensor, tokens_ln: Sequence[torch.Tensor], text_embeddings: torch.Tensor, isd: SD,
+               relu: bool = False, heads: int = 8, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """The IQM glue of AdaptedCLIP.forward (reference model/adapter.py:186-269) + IQM.forward (model/iqm.py:572-673)
+    in eval mode -> iqm_outputs.last_hidden_state [B, 2, hidden].
+      x_final    [B, L, 1024]   the residual stream after the last block (CLS row used, adapter.py:191)
+      tokens_ln  4 x [B, P, 1024]  ln_post of the tapped patch rows (adapter.py:174)
+      text_embeddings [B, 768, 2]  as test_last.py:84 passes them: the branch reads this as 768 "tokens" of width 2
+                                   (adapter.py:229-243), reproduced as executed
+    `isd`: aaclip_hip.synth.synth_iqm_state_dict keys (the reference's parameter names)."""
+    isd = _cast(isd, dtype)
+    x_final, text_embeddings = x_final.to(dtype), text_embeddings.to(dtype)
+    B = x_final.shape[0]
+    cq = torch.relu(_iqm_linear(x_final[:, 0, :], isd, "class_query_mlp.0"))
+    cq = _iqm_linear(cq, isd, "class_query_mlp.2").unsqueeze(1).repeat(1, 2, 1)           # adapter.py:192-196
+    query = cq + isd["pos_embedding"][:, :2, :]                                             # :199-203
+    pk = "fc.0" if relu else "fc"
+    vis = []
+    for i, t in enumerate(tokens_ln):                                                       # :206-208
+        v = t.to(dtype) @ isd[f"query_adapters.{i}.{pk}.weight"].t()
+        vis.append(leaky_relu(v) if relu else v)
+    vis = _iqm_linear(torch.cat(vis, dim=1), isd, "visual_feature_proj")                    # :210-221 (cat over dim 1)
+    assert text_embeddings.dim() == 3 and text_embeddings.shape[1] != 2                     # the branch of :229-235 taken
+    txt = _iqm_linear(text_embeddings, isd, "text_feature_proj")                            # :241-246  [B, 768, 768]
+    h = layer_norm(query, isd["iqm.layernorm.weight"], isd["iqm.layernorm.bias"], 1e-12)    # iqm.py:617
+    layers = sum(1 for k in isd if k.startswith("iqm.encoder.layer.") and k.endswith("attention.attention.query.weight")
+                 and ".crossattention." not in k and ".text_crossattention." not in k)
+    for l in range(layers):                                                                 # IQMLayer.forward :261-343
+        p = f"iqm.encoder.layer.{l}."
+        a = _iqm_attention(h, None, isd, p + "attention.", heads)
+        c = _iqm_attention(a, vis, isd, p + "crossattention.", heads)
+        t = _iqm_attention(c, txt, isd, p + "text_crossattention.", heads)
+        mix = 0.4 * a + 0.3 * c + 0.3 * t                                                   # :311-315
+        inter = gelu_erf(_iqm_linear(mix, isd, p + "intermediate_query.dense"))             # :350-353 (hidden_act gelu)
+        h = layer_norm(_iqm_linear(inter, isd, p + "output_query.dense") + mix, isd[p + "output_query.LayerNorm.weight"],
+                       isd[p + "output_query.LayerNorm.bias"], 1e-12)
+    return layer_norm(h, isd["iqm_layer_norm.weight"], isd["iqm_layer_norm.bias"], 1e-5)   # adapter.py:265
+
+
+def iqm_anomaly_map(seg_tokens: Sequence[torch.Tensor], h: torch.Tensor, img_size: int) -> torch.Tensor:
+    """reference test_last.py:102-138,144: per level sigmoid(cos(f, q_abnormal) - cos(f, q_normal)) on the patch grid,
+    bilinear (align_corners=False) to img_size, summed over levels -> [B, S, S].  (The reference only projects the
+    queries when their width differs from the patch features'; both are 768 here.)"""
+    nq, aq = h[:, 0, :], h[:, 1, :]
+    total = 0
+    for f in seg_tokens:
+        B, P, _ = f.shape
+        g = int(round(P ** 0.5))
+        pred = torch.sigmoid(F.cosine_similarity(f, aq.unsqueeze(1), dim=-1) - F.cosine_similarity(f, nq.unsqueeze(1), dim=-1))
+        total = total + F.interpolate(pred.view(B, 1, g, g), size=(img_size, img_size), mode="bilinear",
+                                      align_corners=False)[:, 0]
+    return total
+
+
+def adapted_visual_forward_iqm(img: torch.Tensor, sd: SD, ia: SD, isd: SD, text_embeddings: torch.Tensor, heads: int,
+                               relu: bool = False, dtype: torch.dtype = torch.float32):
+    """AdaptedCLIP.forward(x, text_embeddings) (reference model/adapter.py:137-271) -> (seg, det, last_hidden_state)."""
+    seg, det, stream = adapted_visual_forward(img, sd, ia, heads, relu=relu, dtype=dtype, return_stream=True)
+    sdc = _cast(sd, dtype)
+    tokens_ln = [layer_norm(x[:, 1:, :], sdc["visual.ln_post.weight"], sdc["visual.ln_post.bias"]) for x in stream]
+    return seg, det, iqm_branch(stream[-1], tokens_ln, text_embeddings, isd, relu=relu, dtype=dtype)
+
+
+# --------------------------------------------------------------------------
 # text side
 # --------------------------------------------------------------------------
 def _text_layers(sd: SD) -> int:

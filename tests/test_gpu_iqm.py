@@ -1,0 +1,190 @@
+"""IQM side branch on the GPU: its small kernels against torch, and the whole branch -- through
+AdaptedCLIP.forward(image, text_embeddings) -- against what the REFERENCE computed with the same seeded weights
+(tests/golden/iqm.npz, made by tests/golden/make_golden_iqm.py) and against the CPU oracle.
+
+Tolerances: exact-fp32 path 2e-4 + 1e-3 |ref| on last_hidden_state (LayerNorm outputs, |values| up to 4.3);
+fp16 path 2e-2 + 2e-2 |ref| there (it is the output of two more transformer layers on top of the fp16 tower, not a
+graded map), and the IQM anomaly maps -- sigmoids of cosine differences, 4 levels summed, values near 2.0 -- at
+1e-3 + 1e-2 |ref| for both."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from aaclip_hip import _lib, engine, synth
+from aaclip_hip._lib import BF16, F16, F32
+from conftest import GOLDEN
+from oracle import aaclip_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+TDT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def close(a, b, atol, rtol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} outside {atol}+{rtol}|ref|, max err {err.max():.3e}"
+    return float(err.max())
+
+
+@pytest.mark.parametrize("kv", [F32, F16, BF16])
+@pytest.mark.parametrize("shape", [(3, 2, 5476, 8, 96), (2, 2, 2, 8, 96), (5, 4, 768, 4, 64), (1, 1, 1, 1, 4),
+                                   (2, 3, 8192, 2, 128)])
+def test_small_attention(dev, kv, shape):
+    B, nq, Lk, H, hd = shape
+    D = H * hd
+    q = synth.randn("iq.q", (B * nq, D), 1.0, 1)
+    k = synth.randn("iq.k", (B * Lk, D), 1.0, 2).to(TDT[kv])
+    v = synth.randn("iq.v", (B * Lk, D), 1.0, 3).to(TDT[kv])
+    out = engine.small_attention(q.to(dev), k.to(dev), v.to(dev), B, nq, Lk, H, kv)
+    qh = q.double().view(B, nq, H, hd).transpose(1, 2)
+    kh = k.double().view(B, Lk, H, hd).transpose(1, 2)
+    vh = v.double().view(B, Lk, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / hd ** 0.5, -1) @ vh).transpose(1, 2).reshape(B * nq, D)
+    close(out, ref, 2e-5, 1e-5, f"small_attention {shape}")      # k, v are exact inputs in every dtype
+
+
+def test_residual_layernorm_combine_smallk_dropcls(dev):
+    lib = _lib.load()
+    a, b = synth.randn("iq.a", (10, 768), 2.0, 1, 0.5), synth.randn("iq.b", (10, 768), 1.0, 2)
+    ln = torch.nn.LayerNorm(768, eps=1e-12)
+    ln.weight.data = synth.randn("iq.w", (768,), 0.2, 3, 1.0)
+    ln.bias.data = synth.randn("iq.bb", (768,), 0.2, 4)
+    out = engine.residual_layernorm(a.to(dev), b.to(dev), ln.to(dev), 1e-12)
+    close(out, O.layer_norm((a + b).double(), ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double(), 1e-12), 1e-5, 1e-5, "res-ln")
+    out = engine.residual_layernorm(a.to(dev), None, ln.to(dev), 1e-5)
+    close(out, O.layer_norm(a.double(), ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double(), 1e-5), 1e-5, 1e-5, "ln")
+    c = synth.randn("iq.c", (10, 768), 1.0, 5)
+    close(engine.combine3(a.to(dev), b.to(dev), c.to(dev), 0.4, 0.3, 0.3), 0.4 * a + 0.3 * b + 0.3 * c, 1e-6, 1e-6, "combine3")
+    close(engine.combine3(a.to(dev), b.to(dev), None, 1.0, 1.0, 0.0), a + b, 1e-6, 1e-6, "combine2")
+    x = synth.randn("iq.x", (3, 768, 2), 0.05, 6)
+    W, bias = synth.randn("iq.W", (768, 2), 1.0, 7), synth.randn("iq.bias", (768,), 0.1, 8)
+    for code in (F32, F16):
+        y = engine.linear_smallk(x.to(dev), W.to(dev), bias.to(dev), code)
+        assert y.shape == (3 * 768, 768) and y.dtype == TDT[code]
+        close(y.float(), (x.double() @ W.double().t() + bias.double()).view(-1, 768), 1e-6 if code == F32 else 2e-3,
+              1e-6 if code == F32 else 2e-3, "linear_smallk")
+    B, L, E = 3, 50, 768
+    for code in (F32, F16, BF16):
+        src = synth.randn("iq.src", (B * L, E), 1.0, 9).to(TDT[code])
+        dst = torch.zeros(B, 4 * (L - 1), E, dtype=TDT[code], device=dev)
+        engine.drop_cls_rows(src.to(dev), dst, B, L, 2 * (L - 1), code)
+        want = torch.zeros(B, 4 * (L - 1), E, dtype=TDT[code])
+        want[:, 2 * (L - 1): 3 * (L - 1)] = src.view(B, L, E)[:, 1:]
+        assert torch.equal(dst.cpu(), want)
+    assert lib.aaclip_small_attention(F16, 1, 1, 1, 1, 2, 5, 10, 8, 96, 0.1, None) < 0     # 5 queries: refused
+    assert lib.aaclip_drop_cls_rows(F16, 1, 1, 2, 50, 768, 100, 60, None) < 0              # rows do not fit
+
+
+def test_iqm_map_vs_oracle(dev):
+    segs = [torch.nn.functional.normalize(synth.randn(f"iq.seg{i}", (3, 1369, 768), 1.0, 11), dim=-1) for i in range(4)]
+    h = synth.randn("iq.h", (3, 2, 768), 1.5, 12)
+    base = synth.randn("iq.base", (3, 518, 518), 1.0, 13)
+    ref = O.iqm_anomaly_map(segs, h, 518)
+    out = engine.iqm_map([s.to(dev) for s in segs], h.to(dev), 518)
+    close(out, ref, 2e-6, 1e-6, "iqm map")
+    fused = engine.iqm_map([s.to(dev) for s in segs], h.to(dev), 518, base=base.to(dev), w_base=0.6, w_iqm=0.4)
+    close(fused, 0.6 * base + 0.4 * ref, 2e-6, 1e-6, "fused map (test_last.py:67-68,141-147)")
+    one = engine.iqm_map([segs[2][:1, :25].to(dev)], h[:1].to(dev), 70)
+    close(one, O.iqm_anomaly_map([segs[2][:1, :25]], h[:1], 70), 2e-6, 1e-6, "5x5 grid, one level")
+
+
+def _build(dev, precision):
+    from model.clip import create_model
+    from model.adapter import AdaptedCLIP
+    cfg = synth.ClipCfg()
+    clip = create_model("ViT-L-14-336", 518, pretrained=None, precision=precision, force_image_size=518)
+    clip.load_state_dict(synth.synth_clip_state_dict(cfg, 111), strict=True)
+    model = AdaptedCLIP(clip, relu=False)
+    model.image_adapter.load_state_dict(synth.synth_image_adapter_state_dict(cfg, seed=111), strict=True)
+    model.text_adapter.load_state_dict(synth.synth_text_adapter_state_dict(cfg, seed=111), strict=True)
+    missing, unexpected = model.load_state_dict(synth.synth_iqm_state_dict(cfg, seed=111), strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith(("clipmodel.", "image_encoder.", "image_adapter.", "text_adapter.")) for k in missing), missing[:4]
+    return model.to(dev).eval()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_iqm_branch_vs_reference_golden(dev, precision):
+    g = np.load(os.path.join(GOLDEN, "iqm.npz"))
+    g4 = np.load(os.path.join(GOLDEN, "full4.npz"))
+    anchors = T(np.load(os.path.join(GOLDEN, "full.npz"))["full.anchors_bottle"])
+    model = _build(dev, precision)
+    img = synth.synth_images(4, 518, seed=int(g4["full4.seed"])).to(dev)
+    te = anchors.unsqueeze(0).repeat(4, 1, 1).to(dev)
+    with torch.no_grad():
+        seg, det, iq = model(img, text_embeddings=te)
+        seg0, det0, none = model(img)
+        maps = engine.iqm_map(seg, iq.last_hidden_state, 518)
+    assert none is None and torch.equal(det, det0) and all(torch.equal(a, b) for a, b in zip(seg, seg0))
+    h = iq.last_hidden_state
+    assert h.shape == (4, 2, 768) and torch.equal(iq.pooler_output, h[:, 0])
+    tol = (2e-4, 1e-3) if precision == "fp32" else (2e-2, 2e-2)
+    e = close(h, T(g["iqm.last_hidden_state"]), *tol, f"last_hidden_state {precision}")
+    print(f"IQM last_hidden_state {precision}: max |err| {e:.3e}")
+    f = maps.reshape(-1).cpu()
+    assert tuple(g["iqm.map_sum.shape"]) == tuple(maps.shape)
+    close(f[T(g["iqm.map_sum.idx"])], T(g["iqm.map_sum.val"]), 1e-3, 1e-2, "IQM map sum (sampled)")
+    close(maps[0][::7, ::7], T(g["iqm.map_sum_full0"]), 1e-3, 1e-2, "IQM map sum (image 0 sub-grid)")
+
+
+def test_iqm_rejects_other_anchor_layouts(dev):
+    cfg = synth.tiny_cfg()
+    from model.model import CLIP
+    from model.adapter import AdaptedCLIP
+    clip = CLIP(cfg.embed_dim, dict(image_size=cfg.image_size, layers=cfg.vision.layers, width=cfg.vision.width,
+                                    patch_size=cfg.patch_size),
+                dict(context_length=77, vocab_size=cfg.vocab_size, width=cfg.text.width, heads=cfg.text.heads,
+                     layers=cfg.text.layers), precision="fp16")
+    clip.load_state_dict(synth.synth_clip_state_dict(cfg, seed=7), strict=True)
+    model = AdaptedCLIP(clip, image_adapt_until=2, levels=[2, 3], relu=False, text_adapt_until=1).to(dev).eval()
+    img = synth.synth_images(2, cfg.image_size, seed=7).to(dev)
+    with torch.no_grad():
+        seg, det, iq = model(img, text_embeddings=torch.randn(2, cfg.embed_dim, 2, device=dev))   # reduced model runs too
+        assert iq.last_hidden_state.shape == (2, 2, 768) and torch.isfinite(iq.last_hidden_state).all()
+        with pytest.raises(NotImplementedError):
+            model(img, text_embeddings=torch.randn(cfg.embed_dim, 2, device=dev))
+
+
+def test_harness_fuses_text_and_iqm_maps_like_the_reference(dev, tmp_path):
+    """test_last.get_predictions with the IQM branch on (reference test_last.py:53-158): maps = 0.6 * text map + 0.4 * IQM
+    map; checked on the exact-fp32 path against the oracle's two maps for a few images of a synthetic MVTec tree."""
+    import dataset as D
+    import test_last as TL
+    from synth_dataset import write_tree
+    root = write_tree(str(tmp_path / "MVTec"))
+    meta = str(tmp_path / "meta" / "MVTec" / "full-shot.jsonl")
+    D.build_metadata(root, meta)
+    model = _build(dev, "fp32")
+    cfg = synth.ClipCfg()
+    anchors = T(np.load(os.path.join(GOLDEN, "full.npz"))["full.anchors_bottle"])
+    ds = D.BaseSingleClassDataset(root, meta, 518, "bottle")
+    n = min(len(ds), 3)
+    sub = torch.utils.data.Subset(ds, list(range(n)))
+    loader = torch.utils.data.DataLoader(sub, batch_size=2)
+    with torch.no_grad():
+        masks, labels, preds, preds_image, names = TL.get_predictions(model, anchors.to(dev), loader, dev, 518, "MVTec")
+        _, _, preds_text, _, _ = TL.get_predictions(model, anchors.to(dev), loader, dev, 518, "MVTec", use_iqm=False)
+    assert preds.shape == (n, 518, 518) and len(names) == n
+    imgs = torch.stack([ds[i]["image"] for i in range(n)])
+    sd = synth.synth_clip_state_dict(cfg, 111)
+    ia = synth.synth_image_adapter_state_dict(cfg, seed=111)
+    isd = synth.synth_iqm_state_dict(cfg, seed=111)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    with torch.no_grad():
+        oseg, odet, oh = O.adapted_visual_forward_iqm(imgs, sd, ia, isd, anchors.unsqueeze(0).repeat(n, 1, 1), cfg.vision.heads)
+        otext = O.anomaly_map(oseg, anchors, 518, "Industrial")
+        oiqm = O.iqm_anomaly_map(oseg, oh, 518)
+    close(T(preds_text), otext, 2e-3, 1e-3, "text map (fp32 path)")
+    close(T(preds), 0.6 * otext + 0.4 * oiqm, 2e-3, 1e-3, "fused map 0.6 text + 0.4 IQM (fp32 path)")

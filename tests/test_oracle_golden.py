@@ -152,3 +152,30 @@ def test_surgery_depends_on_batch_composition(golden_surgery):
     g = golden_surgery
     assert not np.allclose(g["b3.dpam3.tap3"][:1], g["b1.dpam3.tap3"], atol=1e-3)
     assert np.allclose(g["b3.dpam3.tap1"][:1], g["b1.dpam3.tap1"], atol=1e-5)      # block 1 is untouched
+
+
+def test_iqm_branch_vs_reference_golden():
+    """the oracle's IQM branch (model/adapter.py:186-269 + model/iqm.py, eval mode) and the IQM
+    anomaly maps of test_last.py:102-138 against what the REFERENCE computed with the same seeded weights
+    (tests/golden/make_golden_iqm.py), full-size model, B = 4."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "iqm.npz"))
+    g4 = np.load(os.path.join(GOLDEN, "full4.npz"))
+    anchors = T(np.load(os.path.join(GOLDEN, "full.npz"))["full.anchors_bottle"])
+    cfg = synth.ClipCfg()
+    sd = synth.synth_clip_state_dict(cfg, 111)
+    ia = synth.synth_image_adapter_state_dict(cfg, seed=111)
+    isd = synth.synth_iqm_state_dict(cfg, seed=int(g["iqm.seed"]))
+    img = synth.synth_images(4, 518, seed=int(g4["full4.seed"]))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        seg, det, h = O.adapted_visual_forward_iqm(img, sd, ia, isd, anchors.unsqueeze(0).repeat(4, 1, 1), cfg.vision.heads)
+        total = O.iqm_anomaly_map(seg, h, 518)
+    ref = T(g["iqm.last_hidden_state"])
+    assert h.shape == ref.shape == (4, 2, 768)
+    assert float((h - ref).abs().max()) < 2e-4, float((h - ref).abs().max())      # values O(1..4), fp32 both sides
+    f = total.reshape(-1)
+    assert tuple(g["iqm.map_sum.shape"]) == tuple(total.shape)
+    assert float((f[T(g["iqm.map_sum.idx"])] - T(g["iqm.map_sum.val"])).abs().max()) < 2e-5
+    assert float((total[0][::7, ::7] - T(g["iqm.map_sum_full0"])).abs().max()) < 2e-5
