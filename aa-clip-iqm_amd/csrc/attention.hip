@@ -702,10 +702,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn16x2_kernel(const T* __restric
 #endif
     __builtin_amdgcn_s_barrier();
     STAMP(0)
+#ifdef ATTN_DMA_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #if defined(AACLIP_MEASURE) && defined(ATTN_NODMA)
     if (t + PD < nkt && t < 1) stage((t + PD) & 3, t + PD);   // timing ablation (WRONG RESULTS): the ring is filled once
 #else
     if (t + PD < nkt) stage((t + PD) & 3, t + PD);
+#endif
+#ifdef ATTN_DMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
 #endif
     STAMP(1)
     if (active) {
