@@ -50,3 +50,22 @@ def gather_ragged_rows(local: torch.Tensor, total: int, group=None) -> torch.Ten
         b, e = shard_range(total, r, world)
         parts.append(allr[r * mx: r * mx + (e - b)])
     return torch.cat(parts, dim=0)
+
+
+def gather_predictions(arrays, total: int, device=None, group=None):
+    """Evaluation harness across ranks: every rank evaluated the images shard_range(total, rank, world)
+    of one class; `arrays` is its tuple of per-image numpy arrays (masks, labels, anomaly maps, image scores -- any
+    dtypes and trailing shapes, first dimension = its shard size).  Returns the tuple of full arrays in dataset order
+    on every rank, using ONE all-gather per array (ragged shards are padded to the largest, see gather_ragged_rows).
+    `device`: where the collective runs ("cuda:N" for RCCL, None/cpu for gloo)."""
+    import numpy as np
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tuple(arrays)
+    out = []
+    for a in arrays:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if device is not None:
+            t = t.to(device)
+        out.append(gather_ragged_rows(t, total, group).cpu().numpy())
+    return tuple(out)

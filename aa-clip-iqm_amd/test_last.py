@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from aaclip_hip import engine
+from aaclip_hip.shard import gather_predictions, shard_range
 from dataset import DOMAINS, get_dataset
 from forward_utils import calculate_anomaly_map, get_adapted_text_embedding, image_score, metrics_eval
 from model.adapter import AdaptedCLIP
@@ -75,14 +76,33 @@ def get_predictions(model, class_text_embeddings: torch.Tensor, test_loader, dev
 def evaluate(model, image_datasets: Dict[str, torch.utils.data.Dataset], text_embeddings: Dict[str, torch.Tensor],
              device, img_size: int, dataset: str, batch_size: int = 32, loader_kwargs=None, logger=None,
              use_iqm: bool = True) -> List[dict]:
-    """The per-class loop of reference test_last.py:282-326; returns the result rows, last row = Average."""
+    """The per-class loop of reference test_last.py:282-326; returns the result rows, last row = Average.
+    Under torch.distributed (one process per GPU) every rank evaluates a contiguous shard of each
+    class's images -- no communication inside the forward -- and the per-image results are concatenated in dataset
+    order with one all-gather per array (RCCL over xGMI on MI355X); every rank then computes the same table."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
     rows = []
     for class_name, image_dataset in image_datasets.items():
-        loader = torch.utils.data.DataLoader(image_dataset, batch_size=batch_size, shuffle=False, **(loader_kwargs or {}))
-        with torch.no_grad():
-            masks, labels, preds, preds_image, _ = get_predictions(
-                model=model, class_text_embeddings=text_embeddings[class_name], test_loader=loader, device=device,
-                img_size=img_size, dataset=dataset, use_iqm=use_iqm)
+        total = len(image_dataset)
+        if world > 1:
+            b, e = shard_range(total, rank, world)
+            image_dataset = torch.utils.data.Subset(image_dataset, list(range(b, e)))
+        if len(image_dataset) > 0:
+            loader = torch.utils.data.DataLoader(image_dataset, batch_size=batch_size, shuffle=False, **(loader_kwargs or {}))
+            with torch.no_grad():
+                masks, labels, preds, preds_image, _ = get_predictions(
+                    model=model, class_text_embeddings=text_embeddings[class_name], test_loader=loader, device=device,
+                    img_size=img_size, dataset=dataset, use_iqm=use_iqm)
+        else:   # more ranks than images of this class
+            masks = np.zeros((0, 1, img_size, img_size), np.float32)
+            labels, preds_image = np.zeros((0,), np.int64), np.zeros((0,), np.float32)
+            preds = np.zeros((0, img_size, img_size), np.float32)
+        if world > 1:
+            masks, labels, preds, preds_image = gather_predictions(
+                (masks.astype(np.float32), labels.astype(np.int64), preds.astype(np.float32),
+                 preds_image.astype(np.float32)), total, device=device)
         rows.append(metrics_eval(masks, labels, preds, preds_image, class_name, domain=DOMAINS[dataset]))
         if logger:
             logger.info("%s", rows[-1])
@@ -152,7 +172,15 @@ def main(argv=None):
     logger.info("args: %s", vars(args))
     if not torch.cuda.is_available():
         raise RuntimeError("the AA-CLIP HIP path needs an MI355X; there is no CPU fallback")
-    device = torch.device("cuda:0")
+    # one process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): images shard over the ranks, see evaluate()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("AACLIP_BENCH_BACKEND", "nccl"))
     clip_model = create_model(model_name=args.model_name, img_size=args.img_size, device=device, pretrained="openai",
                               require_pretrained=True, precision=args.precision)
     clip_model.eval()
@@ -170,7 +198,10 @@ def main(argv=None):
                     logger=logger, use_iqm=args.iqm == "on")
     table = format_table(rows)
     logger.info("final results:\n%s", table)
-    print(table)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(table)
+    if world > 1:
+        torch.distributed.destroy_process_group()
     return rows
 
 

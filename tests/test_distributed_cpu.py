@@ -52,6 +52,37 @@ def test_two_rank_gather(total):
     mp.spawn(_worker, args=(2, _free_port(), total), nprocs=2, join=True)
 
 
+def _eval_worker(rank, world, port, sizes):
+    """The harness's cross-rank concatenation (test_last.evaluate): per class, every rank holds the results of its
+    shard; gather_predictions must rebuild dataset order on every rank, including classes with fewer images than
+    ranks."""
+    import numpy as np
+    from aaclip_hip.shard import gather_predictions
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for total in sizes:
+            b, e = shard_range(total, rank, world)
+            idx = np.arange(b, e)
+            local = (np.stack([np.full((1, 6, 6), i, np.float32) for i in idx]) if len(idx) else np.zeros((0, 1, 6, 6), np.float32),
+                     idx.astype(np.int64) % 2,
+                     np.stack([np.full((6, 6), 0.5 * i, np.float32) for i in idx]) if len(idx) else np.zeros((0, 6, 6), np.float32),
+                     (idx * 0.25).astype(np.float32))
+            masks, labels, preds, scores = gather_predictions(local, total)
+            ref = np.arange(total)
+            assert masks.shape == (total, 1, 6, 6) and np.array_equal(masks[:, 0, 0, 0], ref.astype(np.float32))
+            assert np.array_equal(labels, ref % 2) and labels.dtype == np.int64
+            assert np.array_equal(preds[:, 3, 3], 0.5 * ref.astype(np.float32))
+            assert np.array_equal(scores, (ref * 0.25).astype(np.float32))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_harness_gathers_sharded_predictions_in_dataset_order():
+    mp.spawn(_eval_worker, args=(2, _free_port(), (7, 8, 1, 3)), nprocs=2, join=True)
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` without torchrun: the process becomes a launcher, starts 2 child ranks before
     touching any GPU, and rank 0 reports n_gpus = ranks_seen = 2 with one all-gather of 2 x batch rows per step.
