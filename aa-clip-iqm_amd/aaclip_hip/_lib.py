@@ -57,6 +57,7 @@ SIGNATURES = {
     "aaclip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _i, _f, _vp]),
     "aaclip_gemm": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
     "aaclip_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "aaclip_attention_log2q": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "aaclip_small_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "aaclip_residual_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),

@@ -211,6 +211,17 @@ int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H,
   return finish("attention");
 }
 
+int aaclip_attention_log2q(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream) {
+  REQUIRE(dtype == AACLIP_F16 || dtype == AACLIP_BF16, "attention_log2q: 16-bit dtypes only");
+  REQUIRE(qkv && ctx, "attention: null pointer");
+  REQUIRE(B > 0 && L > 0 && H > 0, "attention: empty problem");
+  REQUIRE(B <= 65535 && H <= 65535, "attention: grid limit");
+  REQUIRE((long)L * 3 * 64 * H * 4 < (1L << 31), "attention: L * 3 * 64 * H * 4 must stay below 2^31 (32-bit row offsets)");
+  REQUIRE((long)((L + 255) / 256) * H * B < (1L << 30), "attention: too many workgroups");
+  launch_attention(dtype, qkv, ctx, B, L, H, causal, 1, (hipStream_t)stream);
+  return finish("attention");
+}
+
 int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight, void* stream) {
   REQUIRE(x && a && rows > 0, "adapter_mix: bad arguments");
   const char* m = row_width_check(D);

@@ -211,6 +211,10 @@ int aaclip_layernorm(const float* x, const float* w, const float* b, void* out, 
 int aaclip_gemm(int dtype, int epi, const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
                 int M, int N, int K, int act, int scale_cols, float scale, void* stream);
 int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream);
+/* The same with q already in log2 units: q = (x Wq^T + b) * head_dim^-1/2 * log2(e), rounded to `dtype` once -- what
+ * the QKV epilogue of aaclip_block produces (16-bit dtypes only).  This is the kernel variant the block path runs
+ * (one v_exp_f32 per score, no per-score multiply); exported so that it can be tested and timed on its own. */
+int aaclip_attention_log2q(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream);
 int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight, void* stream);
 
 /* ---- IQM side branch (reference model/iqm.py, the glue of model/adapter.py:186-269 and the IQM maps of

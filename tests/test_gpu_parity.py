@@ -170,6 +170,28 @@ def test_attention_online_softmax_rescale(dev):
         assert_close(ctx.float(), ref, 3e-3 if code == F16 else 2e-5, 1e-2 if code == F16 else 1e-5, "spike")
 
 
+@pytest.mark.parametrize("code", [F16, BF16])
+@pytest.mark.parametrize("cfg", [(2, 1370, 2, 0), (1, 640, 3, 1), (3, 77, 4, 1), (1, 50, 1, 0)])
+def test_attention_log2q_variant(dev, code, cfg):
+    """aaclip_attention_log2q: the kernel variant aaclip_block runs (q already in log2 units, one v_exp_f32 per score)
+    against fp64 softmax of (q . k) * ln 2."""
+    lib = _lib.load()
+    B, L, H, causal = cfg
+    D = H * 64
+    qkv = synth.randn("t.attn.l2", (B * L, 3 * D), 1.0, 5)
+    qkv[:, :D] *= 0.6 * 1.4426950408889634
+    qkv = qkv.to(TDT[code])
+    ctx = torch.full((B * L, D), float("nan"), dtype=TDT[code], device=dev)
+    qd = qkv.to(dev)
+    _lib.check(lib.aaclip_attention_log2q(code, qd.data_ptr(), ctx.data_ptr(), B, L, H, causal, stream(dev)))
+    f = qkv.float().clone()
+    f[:, :D] *= 0.6931471805599453
+    ref = _attn_ref(f, B, L, H, causal)
+    tol = (3e-3, 1e-2) if code == F16 else (2.5e-2, 3e-2)
+    assert_close(ctx.float(), ref, tol[0], tol[1], f"attention log2q {cfg}")
+    assert lib.aaclip_attention_log2q(F32, qd.data_ptr(), ctx.data_ptr(), B, L, H, causal, stream(dev)) < 0
+
+
 @pytest.mark.parametrize("causal", [0, 1])
 def test_attention_long_sequence_rebase_paths(dev, causal):
     """The long-sequence kernel (L >= 512) exponentiates against the reference point a row already has and only

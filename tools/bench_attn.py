@@ -15,6 +15,8 @@ ap.add_argument("--H", type=int, default=16)
 ap.add_argument("--causal", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0, help="1 = force the 128-row kernel")
 ap.add_argument("--scale", type=float, default=0.5)
+ap.add_argument("--plain", action="store_true", help="time the plain contract (aaclip_attention: natural-exp scores, a per-score "
+                "multiply) instead of the kernel variant the block path runs (aaclip_attention_log2q)")
 a = ap.parse_args()
 lib = _lib.load()
 lib.aaclip_set_gemm_variant(a.variant << 8)
@@ -26,8 +28,9 @@ qkv[:, :D] *= a.scale
 qkv = qkv.half()
 ctx = torch.empty(B * L, D, device=dev, dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
+fn = lib.aaclip_attention if a.plain else lib.aaclip_attention_log2q   # same scores either way: random q
 def run():
-    _lib.check(lib.aaclip_attention(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, a.causal, st))
+    _lib.check(fn(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, a.causal, st))
 run(); torch.cuda.synchronize()
 fl = 4.0 * B * H * L * L * 64 * (0.5 if a.causal else 1.0)
 ts = []
@@ -39,4 +42,4 @@ for r in range(a.rounds):
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 5)
 ts.sort()
-print(f"attention B={B} L={L} H={H}: median {ts[len(ts)//2]:.3f} ms -> {fl/ts[len(ts)//2]/1e9:.0f} TF")
+print(f"attention ({'plain' if a.plain else 'log2q, block path'}) B={B} L={L} H={H}: median {ts[len(ts)//2]:.3f} ms -> {fl/ts[len(ts)//2]/1e9:.0f} TF")
