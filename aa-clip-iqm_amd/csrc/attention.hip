@@ -1097,6 +1097,149 @@ __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ q
   }
 }
 
+// fp32 attention on the fp32 MATRIX pipe: v_mfma_f32_32x32x2_f32 is an exact fmaf chain (guide section 3) at the
+// fp32 vector rate, so the parity path loses nothing by using it, and unlike the VALU kernel above it runs near that
+// rate: the VALU kernel was 48 % of an exact-fp32 step (432 of 900 ms at B = 64; 27 TFLOP/s).
+// One wave = 32 queries, a workgroup = 4 waves = 128 queries; 32-key tiles, double-buffered in LDS.
+//   S^T[key, q] = K . Q^T : 32 MFMAs (K = 2 each); A operand = K[key = lane%32][d = 2i + lane/32] from a tile stored
+//                 de-interleaved by parity ([parity][key][36]: the pad makes the 8 ds_read_b128 per lane conflict-free),
+//                 B operand = Q (registers, x log2(e))
+//   online softmax on the accumulator: the query is on the lane, its 32 keys are split over the two lane halves
+//   O^T[d, q] += V^T . P^T : 2 x 16 MFMAs; MFMA i takes P element i of each lane as its B operand as it stands (the key
+//                 of element i is (i&3) + 8(i>>2) + 4(lane/32): a sum over keys does not care about their order), and
+//                 the A operand reads that key's row of V.
+__global__ __launch_bounds__(256) void attn32m_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L, int H,
+                                                      int causal) {
+  __shared__ __attribute__((aligned(16))) float Ks[2][2][32][36];
+  __shared__ __attribute__((aligned(16))) float Vs[2][32][64];
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const float* base = qkv + (long)b * L * ld + head * 64;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = q0 + r;
+  const int qrow = qi < L ? qi : L - 1;
+  float qreg[32];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const f32x4 v = *(const f32x4*)(base + (long)qrow * ld + 4 * c);   // d = 4c .. 4c+3; this lane keeps parity h
+    qreg[2 * c] = (h ? v[1] : v[0]) * LOG2E;
+    qreg[2 * c + 1] = (h ? v[3] : v[2]) * LOG2E;
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float m = -1e30f, l = 0.f;   // finite start: a fully masked tile must not produce inf - inf
+  int last_q = blockIdx.x * 128 + 127;
+  if (last_q > L - 1) last_q = L - 1;
+  const int nkt = causal ? (last_q / 32 + 1) : ((L + 31) / 32);
+
+  f32x4 kreg[2], vreg[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j;
+      const int key = idx >> 4, c4 = (idx & 15) * 4;
+      int kg = kt * 32 + key;
+      kg = kg < L ? kg : L - 1;
+      kreg[j] = *(const f32x4*)(base + (long)kg * ld + D + c4);
+      vreg[j] = *(const f32x4*)(base + (long)kg * ld + 2 * D + c4);
+    }
+  };
+  auto store_tile = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j;
+      const int key = idx >> 4, c4 = (idx & 15) * 4;
+      *(f32x2*)&Ks[st][0][key][c4 >> 1] = (f32x2){kreg[j][0], kreg[j][2]};
+      *(f32x2*)&Ks[st][1][key][c4 >> 1] = (f32x2){kreg[j][1], kreg[j][3]};
+      *(f32x4*)&Vs[st][key][c4] = vreg[j];
+    }
+  };
+  auto xswap = [](float& a, float& b2) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2)); };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    if (q0 < L) {
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 kf = *(const f32x4*)&Ks[st][h][r][4 * j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * j + e], s, 0, 0, 0);
+      }
+      const int k0 = kt * 32;
+      if ((k0 + 32 > L) || (causal && (k0 + 31 > q0))) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const bool dead = (key >= L) || (causal && key > qi);
+          s[e] = dead ? -INFINITY : s[e];
+        }
+      }
+      float mt = s[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[e]);
+      {
+        float a = mt, c = mt;
+        xswap(a, c);
+        mt = fmaxf(a, c);
+      }
+      const float mn = fmaxf(m, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] = __builtin_amdgcn_exp2f(s[e] - mn);
+        rs += s[e];
+      }
+      {
+        float a = rs, c = rs;
+        xswap(a, c);
+        rs = a + c;
+      }
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[st][key][r], s[i], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[st][key][32 + r], s[i], o[1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) store_tile(st ^ 1);   // the other stage: everyone left it at the barrier below, one tile ago
+    __syncthreads();
+  }
+  if (qi < L) {
+    const float inv = 1.0f / l;
+    float* dst = ctx + ((long)b * L + qi) * D + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = o[db][4 * g + j] * inv;
+        *(f32x4*)(dst + db * 32 + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
 #ifdef AACLIP_MEASURE
 void read_attn_passes(unsigned long long* out4, int reset) {
   (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_passes), 4 * sizeof(unsigned long long));
@@ -1130,7 +1273,10 @@ bool set_attn_variant(int v) {
 
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
                       hipStream_t s) {
-  if (dtype == AACLIP_F32) {
+  if (dtype == AACLIP_F32 && L >= 64 && g_attn_variant != 1) {   // fp32 MFMA kernel (32 queries per wave)
+    dim3 g((L + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn32m_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
+  } else if (dtype == AACLIP_F32) {                               // short sequences: one query per lane on the VALU
     dim3 g((L + 255) / 256, H, B);
     hipLaunchKernelGGL(attn32_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
 #ifdef AACLIP_MEASURE
