@@ -743,6 +743,487 @@ __global__ __launch_bounds__(NW * 64, 2) void attn16x2_kernel(const T* __restric
   }
 }
 
+#ifdef AACLIP_MEASURE
+// ---------------------------------------------------------------------------
+// Unit-pipelined long-sequence kernel -- an EXPERIMENT, measurement library only (variant 6; tools/attn_ab.py).
+//
+// Stamps of attn16x2_kernel say that inside a wave the MFMA time and the VALU time of a block ADD UP (B2 = 8 MFMAs +
+// 32 v_exp + 32 adds takes 657 cycles = 256 + 259 + 130): a wave issues in order, two adjacent MFMAs serialise on the
+// pipe and only the last MFMA of a chunk has VALU work in its shadow; the pure-MFMA blocks B1 / B4 have none.
+// tools/mfma_valu_slot.hip prices the alternative: [1 MFMA ; <= 24 cycles of VALU] repeats at the MFMA rate (32.3
+// cycles), 2 v_exp + v_cvt_pk + 2 v_add at 37 -- but v_dot2c_f32_f16 or v_pk_add_f32 in the slot WAIT for the MFMA (49).
+//
+// Here the work is cut into UNITS = (32-key sub-tile, 32-row query block): 4 S MFMAs (A), 16 exponentials + 8 packed
+// conversions + 16 adds (E), 4 P.V MFMAs (P).  Unit u's E runs beside A(u+1) and P(u-1): every step is 8 MFMAs, each
+// followed by 2 v_exp + 1 v_cvt_pk + 2 v_add, never two MFMAs back to back.  Consecutive units alternate between the
+// wave's two query blocks, so
+//   * a re-base of unit u (its query block's reference point moves) never touches scores that are already in flight:
+//     A(u+1) belongs to the OTHER query block, A(u+2) is issued after the check;
+//   * the K fragments of a sub-tile serve A of both query blocks, likewise the V^T fragments: all LDS reads of a
+//     sub-tile sit in ONE step and are consumed a step later (no LDS latency on any MFMA's path);
+//   * only two score tuples and two packed-P tuples are live, the row sums stay per lane until the end.
+// The ring's wait + barrier for tile t+1 sits between the two sub-tiles of tile t (the last step of tile t multiplies
+// K(t+1)); the four DMA pieces a wave owes a tile are issued one per step.
+//
+// RESULT: stamped cycles per tile per wave drop from 5.9 k to 4.9 k, and the wall time at B = 64
+// is IDENTICAL to attn16x2_kernel's to three digits (0.643 vs 0.645 ms, also 0.50 vs 0.50 ms on all-zero operands):
+// with every CU busy the chip is power-limited, a kernel that stalls less simply runs at a lower clock.  With few
+// workgroups (B = 1: one per CU, full clock) this kernel is SLOWER (38 vs 32 us): more instructions on the path of a
+// lone wave.  Correct on every attention test; not used by the product library.
+template <typename T, bool LOG2Q, int NW>
+AACLIP_DEV void attn16u_body(char* smem, const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H, int causal,
+                             int b, int head, int qbase) {
+  typedef typename Elem<T>::vec8 vec8;
+  typedef typename Elem<T>::vec4 vec4;
+  typedef typename Elem<T>::vec2 vec2;
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float P_LIMIT = 32768.f;
+  constexpr bool POSTSCALE = !LOG2Q;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const T* base = qkv + (long)b * L * ld + head * 64;
+  const int q0 = qbase + wave * 64;
+  const bool active = q0 < L;   // wave-uniform: idle waves only feed the ring and the barriers
+
+  vec8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int qrow = q0 + qb * 32 + r;
+    qrow = qrow < L ? qrow : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
+  }
+
+  // K/V DMA from inline asm (see attn16x2_body)
+  const unsigned long long ubase = (unsigned long long)base;
+  u32x4 rs;
+  rs[0] = __builtin_amdgcn_readfirstlane((unsigned)ubase);
+  rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(ubase >> 32)) & 0xFFFFu;
+  rs[2] = 0x7FFFFFF0u;
+  rs[3] = 0x00020000u;
+  const int ldb = (int)(ld * sizeof(T));
+  constexpr int NJ = 8 / NW;
+  int kvo[NJ], vvo[NJ], drow[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int pslot = (wave * NJ + j) * 64 + lane;
+    const int row = pslot >> 3, sl = pslot & 7;
+    drow[j] = row;
+    kvo[j] = row * ldb + (D + (sl ^ xk(row)) * 8) * (int)sizeof(T);
+    vvo[j] = row * ldb + (2 * D + (sl ^ xv(row)) * 8) * (int)sizeof(T);
+  }
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ xk(r)) << 4);
+  int voff[2];
+  {
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+    const int row = 4 * (g >> 1) + qq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
+      voff[db] = 8192 + row * 128 + ((chunk ^ xv(row)) << 4) + (pp & 1) * 8;
+    }
+  }
+  int last_q = qbase + NW * 64 - 1;
+  if (last_q > L - 1) last_q = L - 1;
+  const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
+
+  STAMP_DECL   // -DATTN_STAMP: [0] wait + barrier, [1] DMA issue, [2] step a, [3] check a, [4] step b, [5] check b
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + wave * (NJ * 1024);
+  auto dma16 = [&](unsigned lds_addr, int voff_b, int soff_b) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff_b), "s"(rs), "s"(soff_b) : "memory");
+  };
+  auto stage = [&](int st, int kt) {
+    const unsigned dst = lds0 + st * 16384;
+    const int so = __builtin_amdgcn_readfirstlane(kt * 64 * ldb);
+    if (kt * 64 + 64 <= L) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        dma16(dst + j * 1024, kvo[j], so);
+        dma16(dst + 8192 + j * 1024, vvo[j], so);
+      }
+    } else {   // last tile of the key axis: rows beyond L-1 re-read row L-1 (finite data; their scores are masked)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        int over = kt * 64 + drow[j] - (L - 1);
+        over = over > 0 ? over : 0;
+        dma16(dst + j * 1024, kvo[j] - over * ldb, so);
+        dma16(dst + 8192 + j * 1024, vvo[j] - over * ldb, so);
+      }
+    }
+  };
+
+  // One DMA instruction ("piece": 1 KiB of K or V) of tile kt; which = 2 j + (0: K, 1: V).  The four pieces a wave owes
+  // a tile are issued one per STEP, spread over the four steps after the ring barrier that frees the tile's stage:
+  // issued back to back behind the barrier -- by all 8 waves of the CU at once -- they queued for 300 cycles EACH
+  // (stamps: 1264 cycles per tile per wave), a quarter of the tile time with the wave's MFMAs waiting behind them.
+  static_assert(NW == 4, "four DMA pieces per wave and tile, one per step");
+  auto piece = [&](int kt, int which) {
+    if (kt >= nkt) return;   // wave-uniform
+    const int j = which >> 1;
+    const unsigned dst = lds0 + (kt & 3) * 16384 + (which & 1) * 8192 + j * 1024;
+    const int so = __builtin_amdgcn_readfirstlane(kt * 64 * ldb);
+    int off = (which & 1) ? vvo[j] : kvo[j];
+    if (kt * 64 + 64 > L) {   // last tile of the key axis: rows beyond L-1 re-read row L-1
+      int over = kt * 64 + drow[j] - (L - 1);
+      over = over > 0 ? over : 0;
+      off -= over * ldb;
+    }
+    dma16(dst, off, so);
+  };
+
+  f32x16 o[2][2];
+  float m2[2] = {0.f, 0.f}, ll[2] = {0.f, 0.f};   // ll: this LANE's part of the row sum (its 16 keys of every sub-tile)
+  f32x16 cinit[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][db][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[qb][e] = 0.f;
+    asm volatile("" : "+v"(cinit[qb]));
+  }
+  auto xhalf_max = [](float a) {
+    float bb = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bb));
+    return fmaxf(a, bb);
+  };
+  auto xhalf_sum = [](float a) {
+    float bb = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bb));
+    return a + bb;
+  };
+  auto kread = [&](const char* sb, int sub, int ks) { return *(const vec8*)(sb + koff[ks] + sub * 4096); };
+  auto vread = [&](const char* sb, int sub, int s2, int db) {   // V^T fragment: 32 d x 16 keys, transposed LDS read
+    const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
+    i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
+    i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
+    i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(vec8, both);
+  };
+  // dead keys of one unit -> -inf (see mask_sub above); only called under the wave-uniform need_mask branch
+  auto mask_unit = [&](int kt, int sub, int qb, f32x16& s) {
+    asm volatile("" ::: "memory");
+    const int kb = kt * 64 + sub * 32 + 4 * h;
+    int thr = L - kb;
+    if (causal) thr = min(thr, q0 + qb * 32 + r + 1 - kb);
+    asm volatile("" : "+v"(thr));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ce = (e & 3) + 8 * (e >> 2);
+      s[e] = (ce >= thr) ? -INFINITY : s[e];
+    }
+  };
+  // (timing ablations of the measurement library, WRONG RESULTS: -DATTNU_NOEXP, -DATTNU_NOPV, -DATTNU_NOBAR; -DATTNU_ONEWG = one workgroup per CU)
+#if defined(AACLIP_MEASURE) && defined(ATTNU_NOEXP)
+#define ATTNU_EXP(x) ((x) * 0.001f)
+#else
+#define ATTNU_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
+#if defined(AACLIP_MEASURE) && defined(ATTNU_NOPV)
+#define ATTNU_PV(acc, a, b) acc
+#else
+#define ATTNU_PV(acc, a, b) Elem<T>::mma32(a, b, acc)
+#endif
+  // E of a unit in 8 slots, skewed by one slot per dependent instruction so that nothing in a slot waits for a result
+  // of the SAME slot (a v_cvt_pk right behind the two v_exp it packs stalls the wave for the transcendental latency;
+  // stamped: 87 cycles per slot instead of ~32):
+  //   slot i:  2^s of elements 2i, 2i+1  |  pack the pair of slot i-1 into P, add its two values to the row sums
+  // EXP_TAIL finishes slot 7 after the last MFMA of the step.
+#define EXP_E(S, QB, EV, i)                                       \
+  {                                                               \
+    float x0 = S[2 * (i)], x1 = S[2 * (i) + 1];                   \
+    if (POSTSCALE) {                                              \
+      x0 = fmaf(x0, LOG2E, -m2[QB]);                              \
+      x1 = fmaf(x1, LOG2E, -m2[QB]);                              \
+    }                                                             \
+    EV[i][0] = ATTNU_EXP(x0);                                     \
+    EV[i][1] = ATTNU_EXP(x1);                                     \
+    asm volatile("" : "+v"(EV[i][0]), "+v"(EV[i][1]));   /* computed HERE: LLVM sinks pure ops to their first use */ \
+  }
+#define EXP_C(EV, PR, PKV, i)                                     \
+  {                                                               \
+    PR[i] = (vec2){from_float<T>(EV[i][0]), from_float<T>(EV[i][1])}; \
+    asm volatile("" : "+v"(PR[i]));                               \
+    PKV[(i) >> 2][2 * ((i) & 3)] = PR[i][0];                      \
+    PKV[(i) >> 2][2 * ((i) & 3) + 1] = PR[i][1];                  \
+  }
+  // (row sums: plain fp32 adds of the unrounded values.  v_dot2c_f32_f16 on the packed pair -- or v_pk_add_f32 -- halves
+  //  the instruction count but WAITS for the MFMA in flight: tools/mfma_valu_slot.hip, 49 cycles per slot against 37.)
+#define EXP_D(EV, ACC, i) { ACC[0] += EV[i][0]; ACC[1] += EV[i][1]; }
+#define EXP_SLOT(S, QB, PKV, ACC, i)                              \
+  {                                                               \
+    EXP_E(S, QB, ev, i)                                           \
+    if ((i) >= 1) EXP_C(ev, prv, PKV, ((i) >= 1 ? (i) - 1 : 0))   \
+    if ((i) >= 1) EXP_D(ev, ACC, ((i) >= 1 ? (i) - 1 : 0))        \
+  }
+#define EXP_TAIL(PKV, ACC) { EXP_C(ev, prv, PKV, 7) EXP_D(ev, ACC, 7) }
+  // Exact treatment of one unit (rare, out of line): scores recomputed from the LDS tile, true row maximum, the query
+  // block's reference point advanced, O and the row sum re-based, the unit exponentiated again.
+  auto rebase_unit = [&](const char* sb, int kt, int sub, int qb, bool need_mask, f32x16& s, vec8 (&pk)[2], float& rsum) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = Elem<T>::mma32(kread(sb, sub, ks), qf[qb][ks], ks == 0 ? cinit[qb] : s);
+    if (need_mask) mask_unit(kt, sub, qb, s);
+    float a = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) a = fmaxf(a, s[e]);
+    if (POSTSCALE) a = fmaf(a, LOG2E, -m2[qb]);
+    const float mt = xhalf_max(a);
+    float delta = (kt == 0 && sub == 0) ? mt : fmaxf(mt, 0.f);   // very first unit: m = its maximum; later m only grows
+    delta = delta == -INFINITY ? 0.f : delta;                     // every key so far masked: m stays
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    m2[qb] += delta;
+    ll[qb] *= alpha;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
+    if (!POSTSCALE) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] -= delta;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cinit[qb][e] = -m2[qb];
+      asm volatile("" : "+v"(cinit[qb]));
+    }
+    float acc[2] = {0.f, 0.f};
+    float ev[8][2];
+    vec2 prv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) EXP_SLOT(s, qb, pk, acc, i)
+    EXP_TAIL(pk, acc)
+    rsum = acc[0] + acc[1];
+  };
+#define SB0 __builtin_amdgcn_sched_barrier(0)
+
+  // pipeline state between steps
+  f32x16 s0, s1;        // scores of the unit being exponentiated / of the unit after it
+  vec8 kf[4];           // K fragments A(next unit) multiplies
+  vec8 vf[2][2];        // V^T fragments [16-key step][d block] P(previous unit) multiplies
+  vec8 pq0[2], pq1[2];  // packed P of the last unit of query block 0 / 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pq1[i][j] = from_float<T>(0.f);
+      pq0[i][j] = from_float<T>(0.f);
+      vf[i][0][j] = from_float<T>(0.f);
+      vf[i][1][j] = from_float<T>(0.f);
+    }
+  }
+
+  // One sub-tile = two steps.  Entry: s0 = S(sigma, block 0), kf = K(sigma), vf = V(sigma - 1), pq1 = P(sigma - 1, block 1).
+  //   step a:  E(sigma, 0)  ||  P(sigma-1, 1) = O1 += vf . pq1,  A(sigma, 1) = kf . Q1 -> s1;   vf <- V(sigma), kf <- K(sigma+1)
+  //   step b:  E(sigma, 1)  ||  P(sigma, 0)   = O0 += vf . pq0,  A(sigma+1, 0) = kf . Q0 -> s0
+  auto pair = [&](const char* sb, const char* sbn, int kt, int sub, int subn, bool need_mask, int dma_kt, int dma_first) {
+    float rsum;
+    STAMP_START
+    // ---- step a
+    {
+      if (need_mask) mask_unit(kt, sub, 0, s0);
+      float acc[2] = {0.f, 0.f};
+      float ev[8][2];
+      vec2 prv[8];
+      SB0;
+      o[1][0] = ATTNU_PV(o[1][0], vf[0][0], pq1[0]);
+      vf[0][0] = vread(sb, sub, 0, 0);
+      EXP_SLOT(s0, 0, pq0, acc, 0)
+      SB0;
+      s1 = Elem<T>::mma32(kf[0], qf[1][0], cinit[1]);
+      kf[0] = kread(sbn, subn, 0);
+      EXP_SLOT(s0, 0, pq0, acc, 1)
+      SB0;
+      o[1][1] = ATTNU_PV(o[1][1], vf[0][1], pq1[0]);
+      vf[0][1] = vread(sb, sub, 0, 1);
+      EXP_SLOT(s0, 0, pq0, acc, 2)
+      SB0;
+      s1 = Elem<T>::mma32(kf[1], qf[1][1], s1);
+      kf[1] = kread(sbn, subn, 1);
+      EXP_SLOT(s0, 0, pq0, acc, 3)
+      SB0;
+      piece(dma_kt, dma_first);
+      SB0;
+      o[1][0] = ATTNU_PV(o[1][0], vf[1][0], pq1[1]);
+      vf[1][0] = vread(sb, sub, 1, 0);
+      EXP_SLOT(s0, 0, pq0, acc, 4)
+      SB0;
+      s1 = Elem<T>::mma32(kf[2], qf[1][2], s1);
+      kf[2] = kread(sbn, subn, 2);
+      EXP_SLOT(s0, 0, pq0, acc, 5)
+      SB0;
+      o[1][1] = ATTNU_PV(o[1][1], vf[1][1], pq1[1]);
+      vf[1][1] = vread(sb, sub, 1, 1);
+      EXP_SLOT(s0, 0, pq0, acc, 6)
+      SB0;
+      s1 = Elem<T>::mma32(kf[3], qf[1][3], s1);
+      kf[3] = kread(sbn, subn, 3);
+      EXP_SLOT(s0, 0, pq0, acc, 7)
+      SB0;
+      EXP_TAIL(pq0, acc)
+      rsum = acc[0] + acc[1];
+    }
+    STAMP(2)
+    // (evaluated on every unit, the first included: see the note in attn16x2_body)
+    const bool bad0 = __any(!(rsum <= P_LIMIT));
+    if (((kt | sub) == 0) | bad0) rebase_unit(sb, kt, sub, 0, need_mask, s0, pq0, rsum);
+    ll[0] += rsum;
+    SB0;
+    STAMP(3)
+    // ---- step b
+    {
+      if (need_mask) mask_unit(kt, sub, 1, s1);
+      float acc[2] = {0.f, 0.f};
+      float ev[8][2];
+      vec2 prv[8];
+      SB0;
+      o[0][0] = ATTNU_PV(o[0][0], vf[0][0], pq0[0]);
+      EXP_SLOT(s1, 1, pq1, acc, 0)
+      SB0;
+      s0 = Elem<T>::mma32(kf[0], qf[0][0], cinit[0]);
+      EXP_SLOT(s1, 1, pq1, acc, 1)
+      SB0;
+      o[0][1] = ATTNU_PV(o[0][1], vf[0][1], pq0[0]);
+      EXP_SLOT(s1, 1, pq1, acc, 2)
+      SB0;
+      s0 = Elem<T>::mma32(kf[1], qf[0][1], s0);
+      EXP_SLOT(s1, 1, pq1, acc, 3)
+      SB0;
+      piece(dma_kt, dma_first + 1);
+      SB0;
+      o[0][0] = ATTNU_PV(o[0][0], vf[1][0], pq0[1]);
+      EXP_SLOT(s1, 1, pq1, acc, 4)
+      SB0;
+      s0 = Elem<T>::mma32(kf[2], qf[0][2], s0);
+      EXP_SLOT(s1, 1, pq1, acc, 5)
+      SB0;
+      o[0][1] = ATTNU_PV(o[0][1], vf[1][1], pq0[1]);
+      EXP_SLOT(s1, 1, pq1, acc, 6)
+      SB0;
+      s0 = Elem<T>::mma32(kf[3], qf[0][3], s0);
+      EXP_SLOT(s1, 1, pq1, acc, 7)
+      SB0;
+      EXP_TAIL(pq1, acc)
+      rsum = acc[0] + acc[1];
+    }
+    STAMP(4)
+    const bool bad1 = __any(!(rsum <= P_LIMIT));
+    if (((kt | sub) == 0) | bad1) rebase_unit(sb, kt, sub, 1, need_mask, s1, pq1, rsum);
+    ll[1] += rsum;
+    SB0;
+    STAMP(5)
+  };
+
+  // ring prologue: tiles 0, 1 and half of tile 2 in flight, tile 0 confirmed.  Afterwards sub-tile (t, 0) issues pieces
+  // 2, 3 of tile t+2 and sub-tile (t, 1) -- behind the barrier that frees the stage -- pieces 0, 1 of tile t+3.
+  stage(0, 0);
+  if (nkt > 1) stage(1, 1);
+  piece(2, 0);
+  piece(2, 1);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));   // hipcc's wait for the q loads lands here
+  if (nkt > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (active) {   // A(0, block 0), unpipelined
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = kread(smem, 0, ks);
+      s0 = Elem<T>::mma32(kf[ks], qf[0][ks], ks == 0 ? cinit[0] : s0);
+    }
+  }
+#pragma unroll 1
+  for (int t = 0; t < nkt; ++t) {
+    const char* sb = smem + (t & 3) * 16384;
+    const char* sbn = smem + ((t + 1) & 3) * 16384;
+    const int k0 = t * 64;
+    const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));   // wave-uniform
+    if (active) pair(sb, sb, t, 0, 1, need_mask, t + 2, 2);
+    else { piece(t + 2, 2); piece(t + 2, 3); }
+    STAMP_START
+    if (t + 1 < nkt) {
+      // tile t+1 must be complete before the second sub-tile (its last step multiplies K(t+1)); tile t+2 may stay in
+      // flight; every wave is past tile t-1 here, so its stage takes tile t+3
+      if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(AACLIP_MEASURE) && defined(ATTNU_NOBAR))
+      __builtin_amdgcn_s_barrier();
+#endif
+      STAMP(0)
+      STAMP(1)
+    }
+    if (active) pair(sb, sbn, t, 1, 0, need_mask, t + 3, 0);
+    else { piece(t + 3, 0); piece(t + 3, 1); }   // (after the last tile A(t+1, .) multiplies stale LDS: never used)
+  }
+#undef SB0
+#undef EXP_SLOT
+#undef EXP_TAIL
+#undef EXP_E
+#undef EXP_C
+#undef EXP_D
+#undef ATTNU_EXP
+#undef ATTNU_PV
+#if defined(AACLIP_MEASURE) && defined(ATTN_STAMP)
+  if (active && (wave & 3) < 2 && lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_attn_stamp[i], st_acc[i]);
+    atomicAdd(&g_attn_stamp[8], (unsigned long long)nkt);
+  }
+#endif
+  if (active) {
+    // P of the very last unit
+    o[1][0] = Elem<T>::mma32(vf[0][0], pq1[0], o[1][0]);
+    o[1][1] = Elem<T>::mma32(vf[0][1], pq1[0], o[1][1]);
+    o[1][0] = Elem<T>::mma32(vf[1][0], pq1[1], o[1][0]);
+    o[1][1] = Elem<T>::mma32(vf[1][1], pq1[1], o[1][1]);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float lsum = xhalf_sum(ll[qb]);
+      const int qi = q0 + qb * 32 + r;
+      if (qi < L) {
+        const float inv = 1.0f / lsum;
+        T* dst = ctx + ((long)b * L + qi) * D + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            vec4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = from_float<T>(o[qb][db][4 * gi + j] * inv);
+            *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = v;
+          }
+      }
+    }
+  }
+}
+
+template <typename T, bool LOG2Q, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn16u_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H,
+                                                         int causal, int nqt, int total, int per_xcd) {
+#if defined(AACLIP_MEASURE) && defined(ATTNU_ONEWG)   // timing experiment: one workgroup per CU (one wave per SIMD)
+  __shared__ __attribute__((aligned(16))) char smem[98304];
+#else
+  __shared__ __attribute__((aligned(16))) char smem[65536];  // 4 stages x (K 8K + V 8K)
+#endif
+  const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);   // XCD-aware numbering, see attn16x2_kernel
+  if (lin >= total || (int)(blockIdx.x >> 3) >= per_xcd) return;
+  const int qt = lin % nqt, bh = lin / nqt;
+  attn16u_body<T, LOG2Q, NW>(smem, qkv, ctx, L, H, causal, bh / H, bh % H, qt * (NW * 64));
+}
+
+#endif  // AACLIP_MEASURE (unit-pipelined experiment)
+
 #ifdef AACLIP_MEASURE   // software-pipelined variant: measured slower, kept for A/B runs (measurement library)
 // ---------------------------------------------------------------------------
 // Software-pipelined variant (32 query rows per wave, 4-stage K/V ring): the
@@ -1263,7 +1744,7 @@ void read_attn_stamps(unsigned long long* out9, int reset) {
 static int g_attn_variant = 0;  // 1 = always the 2-stage 128-row kernel (A/B measurements)
 bool set_attn_variant(int v) {
 #ifdef AACLIP_MEASURE
-  const bool ok = v >= 0 && v <= 3;   // 2 = software-pipelined 128-query kernel, 3 = long-sequence kernel with 8-wave workgroups
+  const bool ok = (v >= 0 && v <= 3) || v == 6;   // 6 = unit-pipelined experiment (attn16u_kernel)   // 2 = software-pipelined 128-query kernel, 3 = long-sequence kernel with 8-wave workgroups
 #else
   const bool ok = v == 0 || v == 1;
 #endif
@@ -1289,6 +1770,18 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
       if (log2q) hipLaunchKernelGGL((attn16p_kernel<bf16, true>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
       else hipLaunchKernelGGL((attn16p_kernel<bf16, false>), g, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ctx, L, H, causal);
     }
+#endif
+#ifdef AACLIP_MEASURE
+  } else if (L >= 512 && g_attn_variant == 6) {   // unit-pipelined experiment
+    const int nqt = (L + 255) / 256;
+    const long total = (long)nqt * H * B;
+    const int per_xcd = (int)((total + 7) / 8);
+    dim3 g((unsigned)(per_xcd * 8)), blk(256);
+    const int tot = (int)total;
+#define ATTN_LAUNCH_U(TT, LQ) hipLaunchKernelGGL((attn16u_kernel<TT, LQ, 4>), g, blk, 0, s, (const TT*)qkv, (TT*)ctx, L, H, causal, nqt, tot, per_xcd)
+    if (dtype == AACLIP_F16) { if (log2q) ATTN_LAUNCH_U(f16, true); else ATTN_LAUNCH_U(f16, false); }
+    else { if (log2q) ATTN_LAUNCH_U(bf16, true); else ATTN_LAUNCH_U(bf16, false); }
+#undef ATTN_LAUNCH_U
 #endif
   } else if (L >= 512 && g_attn_variant != 1) {
     // 256 queries (4 waves) per workgroup, two workgroups per CU.  512 queries in one 8-wave workgroup halve the K/V

@@ -4,7 +4,7 @@
 import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "aa-clip-iqm_amd")]
-os.environ["AACLIP_LIB"] = os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "libaaclip_hip_measure.so")
+os.environ.setdefault("AACLIP_LIB", os.path.join(REPO, "aa-clip-iqm_amd", "aaclip_hip", "libaaclip_hip_measure.so"))
 import torch
 from aaclip_hip import _lib
 lib = _lib.load()
@@ -20,15 +20,18 @@ qkv = qkv.half()
 ctx = torch.empty(B * L, D, device=dev, dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    _lib.check(lib.aaclip_attention(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, 0, st))
+    _lib.check(lib.aaclip_attention_log2q(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, 0, st))
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()
 f(out, 1)
 for _ in range(5):
-    _lib.check(lib.aaclip_attention(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, 0, st))
+    _lib.check(lib.aaclip_attention_log2q(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, 0, st))
 torch.cuda.synchronize()
 f(out, 0)
-names = ["wait+barrier", "DMA issue", "B1 S0 chains", "B2 S1 || exp S0", "check0 (+rare)", "B3 PV0 || exp S1", "check1 (+rare)", "B4 PV1 + sums"]
+if int(os.environ.get("ATTN_VARIANT", "0")) != 6:   # block-pipelined kernel (attn16x2)
+    names = ["wait+barrier", "DMA issue", "B1 S0 chains", "B2 S1 || exp S0", "check0 (+rare)", "B3 PV0 || exp S1", "check1 (+rare)", "B4 PV1 + sums"]
+else:                                          # unit-pipelined experiment (attn16u): two sub-tiles per tile
+    names = ["wait+barrier", "DMA issue", "steps a (x2)", "checks a (x2)", "steps b (x2)", "checks b (x2)", "-", "-"]
 tiles = out[8]
 tot = sum(out[i] for i in range(8))
 for i, n in enumerate(names):
