@@ -137,6 +137,35 @@ def test_full_b4_adapted_forward_vs_reference_golden(dev, g4, weights, code):
 
 
 @pytest.mark.parametrize("code", [F32, F16])
+def test_full_b4_fp16_native_weights(dev, weights, code):
+    """The deployment case: CLIP weights that are exactly representable in fp16 (OpenAI's checkpoint is stored in fp16
+    and the reference widens it on load, model/clip.py:88), so the fp16 path's weight conversion is lossless and only
+    the ACTIVATION rounding of the tower is left.  Golden: the reference run with the seeded CLIP weights rounded
+    through fp16 (tests/golden/make_golden_full4h.py).  Asserted at the same bounds as the fp32-weight record; the
+    actual errors go to parity_errors.json next to it (`*.b4h.*`) -- the measured difference between the two records
+    is the share of the map error that came from rounding fp32 weights, which real checkpoints do not have."""
+    g = np.load(os.path.join(GOLDEN, "full4h.npz"))
+    cfg, sd, ia, ta = weights
+    sdh = {k: (v.half().float() if v.is_floating_point() else v) for k, v in sd.items()}
+    model = build(dev, NAME[code], (cfg, sdh, ia, ta))
+    tag = NAME[code]
+    with torch.no_grad():
+        seg, det, _ = model(synth.synth_images(4, 518, seed=int(g["full4h.seed"])).to(dev))
+    atol, rtol = FEATURE_TOL[code]
+    for i in range(4):
+        a_, b_ = sampled(g, f"full4h.seg{i}", seg[i])
+        compare(f"{tag}.b4h.seg{i}", a_, b_, atol, rtol)
+    compare(f"{tag}.b4h.det", det, T(g["full4h.det"]), atol, rtol)
+    anchors = T(np.load(os.path.join(GOLDEN, "full.npz"))["full.anchors_bottle"]).to(dev)
+    (la, lr), (sa, sr) = MAP_TOL[code]
+    for i in range(4):
+        raw = engine.anomaly_map([seg[i]], anchors, 37, 1, 1.0)
+        compare(f"{tag}.b4h.map_pre_blur{i}", raw, T(g[f"full4h.map_pre_blur{i}"]), la, lr)
+    fused = engine.anomaly_map(list(seg), anchors, 37, 1, 1.0)
+    compare(f"{tag}.b4h.map_pre_blur_sum", fused, T(g["full4h.map_pre_blur_sum"]), sa, sr)
+
+
+@pytest.mark.parametrize("code", [F32, F16])
 def test_full_b4_encode_image_taps_vs_reference_golden(dev, g4, weights, code):
     """BASELINE config 2 as written -- CLIP.encode_image(image, [6, 12, 18, 24]) -- on the large-batch kernels
     (256-tile GEMMs, ln folds, aaclip_blocks_to taps without copies) vs the reference's B = 4 numbers."""
