@@ -117,7 +117,11 @@ def test_measurement_library_has_no_substitute_kernels():
             rc = m.aaclip_gemm(_lib.F16, epi, 0x7f0000001000, K, 0x7f0000002000, 0x7f0000003000, 0x7f0000004000, N,
                                M, N, K, 0, 0, 1.0, None)
             assert rc < 0 and b"fp32-output epilogue only" in m.aaclip_last_error(), (variant, epi)
-    assert m.aaclip_set_gemm_variant(61) < 0 and m.aaclip_set_gemm_variant(3 << 8) < 0
+    assert m.aaclip_set_gemm_variant(61) < 0
+    for av in (4, 5, 7):                                         # attention variants: 0-3 and 6 exist
+        assert m.aaclip_set_gemm_variant(av << 8) < 0, av
+    for av in (3, 6, 0):
+        assert m.aaclip_set_gemm_variant(av << 8) == 0, av
     assert m.aaclip_set_gemm_variant(0) == 0
 
 
