@@ -770,12 +770,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn16x2_kernel(const T* __restric
 // with every CU busy the chip is power-limited, a kernel that stalls less simply runs at a lower clock.  With few
 // workgroups (B = 1: one per CU, full clock) this kernel is SLOWER (38 vs 32 us): more instructions on the path of a
 // lone wave.  Correct on every attention test; not used by the product library.
+template <typename T> struct Pair16;   // two 16-bit values in one register
+template <> struct Pair16<f16> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
+template <> struct Pair16<bf16> { typedef __bf16 type __attribute__((ext_vector_type(2))); };
 template <typename T, bool LOG2Q, int NW>
 AACLIP_DEV void attn16u_body(char* smem, const T* __restrict__ qkv, T* __restrict__ ctx, int L, int H, int causal,
                              int b, int head, int qbase) {
   typedef typename Elem<T>::vec8 vec8;
   typedef typename Elem<T>::vec4 vec4;
-  typedef typename Elem<T>::vec2 vec2;
+  typedef typename Pair16<T>::type vec2;
   typedef short i16x8 __attribute__((ext_vector_type(8)));
   constexpr float LOG2E = 1.4426950408889634f;
   constexpr float P_LIMIT = 32768.f;

@@ -25,20 +25,16 @@ template <typename T> struct Elem;
 template <> struct Elem<f16> {
   typedef f16x8 vec8;
   typedef f16x4 vec4;
-  typedef _Float16 vec2 __attribute__((ext_vector_type(2)));
   static AACLIP_DEV f32x16 mma32(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
-
 };
 template <> struct Elem<bf16> {
   typedef bf16x8 vec8;
   typedef bf16x4 vec4;
-  typedef __bf16 vec2 __attribute__((ext_vector_type(2)));
   static AACLIP_DEV f32x16 mma32(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
-
 };
 
 template <typename T> AACLIP_DEV T from_float(float v) { return (T)v; }
