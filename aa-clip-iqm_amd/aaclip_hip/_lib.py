@@ -45,6 +45,7 @@ SIGNATURES = {
     "aaclip_block": (_i, [_vp, C.POINTER(BlockWeights), _f] + [_i] * 7 + [_vp, _sz, _vp]),
     "aaclip_blocks": (_i, [_vp, C.POINTER(BlockWeights), _i, _f] + [_i] * 7 + [_vp, _sz, _vp]),
     "aaclip_blocks_to": (_i, [_vp, _vp, C.POINTER(BlockWeights), _i, _f] + [_i] * 7 + [_vp, _sz, _vp]),
+    "aaclip_blocks_taps": (_i, [_vp, C.POINTER(_vp), C.POINTER(BlockWeights), _i, _f] + [_i] * 7 + [_vp, _sz, _vp]),
     "aaclip_tap_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "aaclip_det_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "aaclip_anomaly_map": (_i, [C.POINTER(_vp), _i, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),

@@ -251,11 +251,13 @@ def run_block(x: torch.Tensor, block, B: int, L: int, heads: int, code: int, cau
 
 def run_blocks(x: torch.Tensor, blocks: Sequence, B: int, L: int, heads: int, code: int, causal: bool = False,
                adapter_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, mix: float = 0.0,
-               x_out: Optional[torch.Tensor] = None) -> None:
+               x_out: Optional[torch.Tensor] = None, x_outs: Optional[Sequence[torch.Tensor]] = None) -> None:
     """Consecutive blocks in ONE aaclip_blocks call (in place on x [B*L, D]); nothing reads x in between, so
     the library folds ln_1 of every block but the first into its QKV product.  Blocks flagged by
     DAPM_replace run their V-V attention; a run must not mix the two attention modes.
-    x_out: leave x untouched and continue the stream in x_out (aaclip_blocks_to) -- x stays valid as a tap."""
+    x_out: leave x untouched and continue the stream in x_out (aaclip_blocks_to) -- x stays valid as a tap.
+    x_outs: one tensor per block = the buffer holding the stream after that block (aaclip_blocks_taps): a buffer
+    that later blocks do not write again is a tap, and the whole tower is one call."""
     blocks = list(blocks)
     if not blocks:
         return
@@ -282,6 +284,19 @@ def run_blocks(x: torch.Tensor, blocks: Sequence, B: int, L: int, heads: int, co
         require_gpu(x_out, "block")
         if x_out.shape != x.shape or x_out.dtype != torch.float32 or not x_out.is_contiguous():
             raise ValueError("x_out must be a contiguous fp32 tensor of x's shape")
+    if x_outs is not None:
+        if x_out is not None or len(x_outs) != len(blocks):
+            raise ValueError("x_outs: one output tensor per block (and no x_out)")
+        ptrs = (C.c_void_p * len(blocks))()
+        for i, t in enumerate(x_outs):
+            require_gpu(t, "block")
+            if t.shape != x.shape or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("x_outs must be contiguous fp32 tensors of x's shape")
+            ptrs[i] = t.data_ptr()
+        _lib.check(lib.aaclip_blocks_taps(x.data_ptr(), ptrs, arr, len(blocks), float(mix), B, L, D, heads, F, mode,
+                                          code, ws.data_ptr(), ws.numel(), _stream(x.device)), "blocks")
+        del refs
+        return
     dst = x if x_out is None else x_out
     _lib.check(lib.aaclip_blocks_to(x.data_ptr(), dst.data_ptr(), arr, len(blocks), float(mix), B, L, D, heads, F, mode,
                                     code, ws.data_ptr(), ws.numel(), _stream(x.device)), "blocks")

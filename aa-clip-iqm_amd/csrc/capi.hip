@@ -447,8 +447,12 @@ int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float m
   return aaclip_blocks_to(x, x, w, n_blocks, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, stream);
 }
 
-int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L,
-                     int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream) {
+// x_out[i] (x_of(i)) = the buffer holding the stream after block i; block i reads the stream from x_in (i == 0) or
+// from the buffer block i-1 wrote.  x_out == nullptr: every block writes x_all.
+static int blocks_core(const float* x_in, float* const* x_out, float* x_all, const aaclip_block_weights* w, int n_blocks,
+                       float mix, int B, int L, int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes,
+                       void* stream) {
+  float* x = x_out ? x_out[0] : x_all;
   REQUIRE(x_in && w, "block: null pointer");
   REQUIRE(n_blocks >= 1, "block: n_blocks must be positive");
   // a caller built against another header revision (no size field, fewer pointer fields) is refused here, before
@@ -473,15 +477,33 @@ int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w,
   const long rows = (long)B * L;
   REQUIRE(rows < (1L << 31) / 4, "block: too many rows");
   REQUIRE(ws_bytes >= aaclip_workspace_bytes(dtype, rows, D, F, 0), "block: workspace too small");
+  if (x_out)
+    for (int i = 0; i < n_blocks; ++i) REQUIRE(x_out[i], "block: null output buffer");
   bool aux = false;
+  const float* src = x_in;
   for (int i = 0; i < n_blocks; ++i) {
     bool produced = false;
-    int rc = block_impl(i == 0 ? x_in : x, x, w + i, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes,
-                        (hipStream_t)stream, aux, i + 1 < n_blocks, &produced);
+    float* dst = x_out ? x_out[i] : x_all;
+    int rc = block_impl(src, dst, w + i, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, (hipStream_t)stream, aux,
+                        i + 1 < n_blocks, &produced);
     if (rc) return rc;
     aux = produced;
+    src = dst;
   }
   return finish("block");
+}
+
+int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L,
+                     int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(x, "block: null pointer");
+  return blocks_core(x_in, nullptr, x, w, n_blocks, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, stream);
+}
+
+int aaclip_blocks_taps(const float* x_in, float* const* x_out, const aaclip_block_weights* w, int n_blocks, float mix,
+                       int B, int L, int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes,
+                       void* stream) {
+  REQUIRE(x_out && n_blocks >= 1, "block: null output list");
+  return blocks_core(x_in, x_out, nullptr, w, n_blocks, mix, B, L, D, H, F, attn_mode, dtype, ws, ws_bytes, stream);
 }
 
 int aaclip_block(float* x, const aaclip_block_weights* w, float mix, int B, int L, int D, int H, int F, int attn_mode,

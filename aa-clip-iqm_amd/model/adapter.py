@@ -94,34 +94,30 @@ class AdaptedCLIP(nn.Module):
         code = self._code()
         v = self.image_encoder
         xs, B, L = engine.patch_embed(x, v, code)
-        heads = v.num_heads
         adapters = self.image_adapter["layer_adapters"]
-        seg_tokens: List[torch.Tensor] = []
-        det_token = None
         n_levels = len(self.levels)
         blocks = list(v.transformer.resblocks)
         iqm_on = text_embeddings is not None
         dt = engine.torch_dtype(code)
         P = L - 1
         vis_cat = torch.empty(B, n_levels * P, self.iqm_hidden_size, dtype=dt, device=xs.device) if iqm_on else None
-        run, run_aw = [], []   # consecutive blocks up to the next tap: one aaclip_blocks call
-        for i, blk in enumerate(blocks):
-            run.append(blk)
-            run_aw.append(adapters[i].weight if i < self.image_adapt_until else None)
-            if (i + 1) in self.levels or i + 1 == len(blocks):
-                engine.run_blocks(xs, run, B, L, heads, code, causal=False, adapter_weights=run_aw, mix=self.i_w)
-                run, run_aw = [], []
-            if (i + 1) in self.levels:
-                k = len(seg_tokens)
-                last = k == n_levels - 1
-                seg, det = engine.tap_head(
-                    xs, v.ln_post, self.image_adapter["seg_proj"][k].weight, self.relu, B, L, code,
-                    det_weight=self.image_adapter["det_proj"].weight if last else None)
-                seg_tokens.append(seg)
-                if last:
-                    det_token = det
-                if iqm_on:
-                    self._iqm_project_level(xs, k, vis_cat, B, L, code)
+        # the whole tower with its adapters in ONE library call; the stream after every level stays in its own buffer
+        # (no copies: the block behind a tap continues in a fresh one), the heads read them afterwards
+        aws = [adapters[i].weight if i < self.image_adapt_until else None for i in range(len(blocks))]
+        levels = [lv for lv in range(1, len(blocks) + 1) if lv in self.levels]
+        xs, taps = v.transformer.run(xs, B, L, code, False, levels, adapter_weights=aws, mix=self.i_w)
+        seg_tokens: List[torch.Tensor] = []
+        det_token = None
+        for k, tap in enumerate(taps):
+            last = k == n_levels - 1
+            seg, det = engine.tap_head(
+                tap, v.ln_post, self.image_adapter["seg_proj"][k].weight, self.relu, B, L, code,
+                det_weight=self.image_adapter["det_proj"].weight if last else None)
+            seg_tokens.append(seg)
+            if last:
+                det_token = det
+            if iqm_on:
+                self._iqm_project_level(tap, k, vis_cat, B, L, code)
         if not iqm_on:
             return seg_tokens, det_token, None
         return seg_tokens, det_token, self._iqm_branch(xs, vis_cat, text_embeddings, B, L, code)

@@ -123,29 +123,33 @@ class Transformer(nn.Module):
     def get_cast_dtype(self) -> torch.dtype:
         return self.resblocks[0].mlp.c_fc.weight.dtype
 
-    def run(self, x: torch.Tensor, B: int, L: int, code: int, causal: bool, out_layers: Sequence[int] = ()):
+    def run(self, x: torch.Tensor, B: int, L: int, code: int, causal: bool, out_layers: Sequence[int] = (),
+            adapter_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, mix: float = 0.0):
         """Batch-first tower -> (final stream, [stream after the 1-based layers in out_layers]) (reference
         transformer.py:295-317).  Without taps the tower runs in place on x; a tapped buffer is never written
         again (the next run continues in a fresh one), so taps cost no copy and the final stream may live in a
-        different tensor than x."""
+        different tensor than x.  The library sees the whole tower (aaclip_blocks_taps), so ln_1 is folded into the
+        QKV product behind a tap as well.  adapter_weights[i] (or None) = the residual adapter applied after block i
+        (reference model/adapter.py:163-170), mixed in with weight `mix`."""
         taps = []
-        run: list = []   # consecutive blocks nobody looks between: one aaclip_blocks call
+        run: list = []     # consecutive blocks of one attention mode: ONE aaclip_blocks_taps call, taps included
+        outs: list = []    # per block of the run: the buffer holding the stream after it
         n = len(self.resblocks)
-        cur = x          # buffer holding the stream; after a tap the next run continues in a fresh one
+        cur = x            # buffer holding the stream; after a tap the next block continues in a fresh one
+        src = x            # what the run's first block reads
+        first = 0          # index of the run's first block
         tapped = False
         for i, blk in enumerate(self.resblocks):
+            if tapped:     # `cur` was handed out as a tap: read it, write the continuation elsewhere (no copy)
+                cur, tapped = torch.empty_like(cur), False
             run.append(blk)
+            outs.append(cur)
             nxt = self.resblocks[i + 1] if i + 1 < n else None
-            boundary = (i + 1) in out_layers or nxt is None or \
-                bool(getattr(nxt, "surgery", False)) != bool(getattr(blk, "surgery", False))
-            if boundary:
-                if tapped:   # `cur` was handed out as a tap: read it, write the continuation elsewhere (no copy)
-                    fresh = torch.empty_like(cur)
-                    engine.run_blocks(cur, run, B, L, self.heads, code, causal=causal, x_out=fresh)
-                    cur, tapped = fresh, False
-                else:
-                    engine.run_blocks(cur, run, B, L, self.heads, code, causal=causal)
-                run = []
+            if nxt is None or bool(getattr(nxt, "surgery", False)) != bool(getattr(blk, "surgery", False)):
+                aws = adapter_weights[first:i + 1] if adapter_weights is not None else None
+                engine.run_blocks(src, run, B, L, self.heads, code, causal=causal, adapter_weights=aws, mix=mix,
+                                  x_outs=outs)
+                run, outs, src, first = [], [], cur, i + 1
             if (i + 1) in out_layers:
                 taps.append(cur)
                 tapped = True

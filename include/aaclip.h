@@ -121,6 +121,17 @@ int aaclip_blocks(float* x, const aaclip_block_weights* w, int n_blocks, float m
 int aaclip_blocks_to(const float* x_in, float* x, const aaclip_block_weights* w, int n_blocks, float mix, int B, int L,
                      int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* A whole tower with taps in ONE call: x_out[i] is the buffer that holds the stream AFTER block i; block i reads
+ * the stream from x_in (i = 0) or from x_out[i-1] and writes x_out[i] (in place when they are the same buffer; a buffer
+ * that is not written again keeps the tower's state at that layer).  Equivalent to one aaclip_blocks_to call per run
+ * of blocks between taps, except that the library sees the whole sequence, so ln_1 of the first block after a tap is
+ * folded into its QKV product like every other (those calls run it as a LayerNorm pass: nothing tells them that the
+ * workspace still holds the previous call's rows).  Reference: model/transformer.py:295-317 (out_layers),
+ * model/adapter.py:160-172 (levels). */
+int aaclip_blocks_taps(const float* x_in, float* const* x_out, const aaclip_block_weights* w, int n_blocks, float mix,
+                       int B, int L, int D, int H, int F, int attn_mode, int dtype, void* ws, size_t ws_bytes,
+                       void* stream);
+
 /* Tap head: ln_post -> seg_proj (Linear no bias [+LeakyReLU]) -> F.normalize, CLS row
  * dropped.  Replaces reference model/adapter.py:171-182.  x [B*L, D] fp32 (tap of the
  * residual stream); proj_w [E, D] dtype; seg_out [B, L-1, E] fp32 unit rows.

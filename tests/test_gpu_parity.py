@@ -712,6 +712,47 @@ def test_blocks_run_folds_ln1_across_blocks(dev, full_weights, code):
     assert_close(xa, xb, atol, rtol, "one call vs block by block")
 
 
+@pytest.mark.parametrize("B", [2, 4])
+def test_blocks_taps_one_call_vs_one_call_per_run(dev, full_weights, B):
+    """aaclip_blocks_taps (the whole tower with its taps in one call: per-block output buffers) against one
+    aaclip_blocks_to call per run between taps.  B = 2 (small-batch kernels, LayerNorm passes everywhere): identical
+    bits.  B = 4 (large-batch kernels): the one-call form also folds ln_1 of the first block behind a tap, which the
+    per-run calls run as a pass -- equal within the fp16 tolerance, taps untouched by later blocks, and both against
+    the oracle."""
+    cfg, sd, ia, ta = full_weights
+    model = build_full(dev, "fp16", full_weights)
+    blocks = list(model.image_encoder.transformer.resblocks[3:9])
+    aws = [model.image_adapter["layer_adapters"][i].weight if i < 6 else None for i in range(3, 9)]
+    L, D = 1370, 1024
+    x0 = synth.randn("t.taps.x", (B * L, D), 1.0, 23)
+    # one call: blocks 3,4 in place on a; tap; blocks 5,6,7 in b; tap; block 8 in c
+    a, b, c = x0.clone().to(dev), torch.empty(B * L, D, device=dev), torch.empty(B * L, D, device=dev)
+    engine.run_blocks(a, blocks, B, L, 16, F16, adapter_weights=aws, mix=0.1, x_outs=[a, a, b, b, b, c])
+    # one call per run
+    a2, b2, c2 = x0.clone().to(dev), torch.empty(B * L, D, device=dev), torch.empty(B * L, D, device=dev)
+    engine.run_blocks(a2, blocks[:2], B, L, 16, F16, adapter_weights=aws[:2], mix=0.1)
+    engine.run_blocks(a2, blocks[2:5], B, L, 16, F16, adapter_weights=aws[2:5], mix=0.1, x_out=b2)
+    engine.run_blocks(b2, blocks[5:], B, L, 16, F16, adapter_weights=aws[5:], mix=0.1, x_out=c2)
+    assert torch.equal(a, a2)                       # the first run is the same sequence of launches either way
+    if B == 2:
+        assert torch.equal(b, b2) and torch.equal(c, c2)
+    else:
+        assert_close(b, b2, 6e-3, 1e-2, "tap 2: one call vs per-run calls")
+        assert_close(c, c2, 6e-3, 1e-2, "final: one call vs per-run calls")
+        assert not torch.equal(b, b2)               # ln_1 behind the tap really ran folded
+    ref = x0.view(B, L, D).double()
+    sdd = {k: v.double() for k, v in sd.items()}
+    refs = {}
+    for i in range(3, 9):
+        ref = O.resblock(ref, sdd, f"visual.transformer.resblocks.{i}.", 16, None)
+        if i < 6:
+            ref = O.adapter_mix(ref, ia[f"layer_adapters.{i}.fc.0.weight"].double(), 0.1)
+        refs[i] = ref.view(B * L, D)
+    assert_close(a, refs[4], 6e-3, 1e-2, "tap 1 vs oracle")
+    assert_close(b, refs[7], 6e-3, 1e-2, "tap 2 vs oracle")
+    assert_close(c, refs[8], 6e-3, 1e-2, "final vs oracle")
+
+
 def test_text_tower_large_batch_folds_like_small_batches(dev, full_weights):
     """encode_text on 64 sentences (M = 4928 rows: the 256-tile kernels with LayerNorm folding, width 768, causal)
     against the same sentences encoded 8 at a time (128-tile kernels, LayerNorm passes) and against the oracle."""
