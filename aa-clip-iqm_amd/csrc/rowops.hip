@@ -446,17 +446,24 @@ namespace aaclip {
 // LayerNorm folding: per-row partial (sum, sum of squares) of the 16-bit residual rows, one pair per 64-column
 // slice in a fixed order (deterministic), -> (a, b) = (rstd, -mean * rstd) with the biased variance and eps
 // of nn.LayerNorm (reference model/transformer.py:37-43).
+// 16 lanes per row (one per 64-column slice: coalesced 128-byte lines instead of one strided 8-byte load per lane and
+// slice), summed over the lane row by DPP rotations -- a fixed order, so results do not depend on the batch.
+AACLIP_DEV float row16_total(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+  return x;
+}
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ ab,
                                                                 long rows, int slots, float inv_d, float eps) {
-  const long row = (long)blockIdx.x * 256 + threadIdx.x;
-  if (row >= rows) return;
-  const f32x2* p = (const f32x2*)(partials + row * slots * 2);
-  float s = 0.f, q = 0.f;
-  for (int i = 0; i < slots; ++i) {
-    const f32x2 v = p[i];
-    s += v[0];
-    q += v[1];
-  }
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = t >> 4;
+  const int slot = (int)(t & 15);
+  f32x2 v = {0.f, 0.f};
+  if (row < rows && slot < slots) v = *(const f32x2*)(partials + (row * slots + slot) * 2);
+  const float s = row16_total(v[0]), q = row16_total(v[1]);
+  if (row >= rows || slot != 0) return;
   const float mean = s * inv_d;
   float var = q * inv_d - mean * mean;
   var = var > 0.f ? var : 0.f;
@@ -465,7 +472,8 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
   *(f32x2*)(ab + 2 * row) = o;
 }
 void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s) {
-  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, ab, rows,
+  // slots = D / 64 <= 16 (row widths up to 1024, checked by row_width_check)
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, partials, ab, rows,
                      slots, 1.0f / D, eps);
 }
 }  // namespace aaclip
