@@ -40,6 +40,24 @@ __global__ __launch_bounds__(256) void small_attention_kernel(const float* __res
   for (int j = tid; j < Lk; j += 256) {
     const T* kr = k + ((long)b * Lk + j) * D + h * hd;
     float s[SA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+    if (sizeof(T) == 2 && (hd & 7) == 0 && (D & 7) == 0) {
+      // 16-byte loads (the row slice of a head starts on a 16-byte boundary when hd and D are multiples of 8); the
+      // products are summed in the same element order as the 4-wide loop below
+      typedef T t8 __attribute__((ext_vector_type(8)));
+      for (int d = 0; d < hd; d += 8) {
+        const t8 kv = *(const t8*)(kr + d);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float k0 = (float)kv[4 * half], k1 = (float)kv[4 * half + 1], k2 = (float)kv[4 * half + 2],
+                      k3 = (float)kv[4 * half + 3];
+          const int dd = d + 4 * half;
+#pragma unroll
+          for (int a = 0; a < SA_MAXQ; ++a)
+            if (a < nq)
+              s[a] = fmaf(k3, qs[a][dd + 3], fmaf(k2, qs[a][dd + 2], fmaf(k1, qs[a][dd + 1], fmaf(k0, qs[a][dd], s[a]))));
+        }
+      }
+    } else
     for (int d = 0; d < hd; d += 4) {
       const float k0 = ldf(kr + d), k1 = ldf(kr + d + 1), k2 = ldf(kr + d + 2), k3 = ldf(kr + d + 3);
 #pragma unroll
@@ -81,16 +99,37 @@ __global__ __launch_bounds__(256) void small_attention_kernel(const float* __res
 #pragma unroll
   for (int a = 0; a < SA_MAXQ; ++a) acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0.f;
   if (sl < slices) {
-    for (int j = sl; j < Lk; j += slices) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    const bool vec = (hd & 3) == 0 && (D & 3) == 0;
+    auto loadv = [&](int j, float (&o4)[4]) {
       const T* vr = v + ((long)b * Lk + j) * D + h * hd + c * 4;
-      const float v0 = ldf(vr), v1 = ldf(vr + 1), v2 = ldf(vr + 2), v3 = ldf(vr + 3);
+      if (vec) {                              // one 8- / 16-byte load
+        const t4 vv = *(const t4*)vr;
+        o4[0] = (float)vv[0]; o4[1] = (float)vv[1]; o4[2] = (float)vv[2]; o4[3] = (float)vv[3];
+      } else {
+        o4[0] = ldf(vr); o4[1] = ldf(vr + 1); o4[2] = ldf(vr + 2); o4[3] = ldf(vr + 3);
+      }
+    };
+    auto fma4 = [&](int j, const float (&v4)[4]) {
 #pragma unroll
       for (int a = 0; a < SA_MAXQ; ++a)
         if (a < nq) {
           const float p = sm[a * Lk + j];
-          acc[a][0] = fmaf(p, v0, acc[a][0]); acc[a][1] = fmaf(p, v1, acc[a][1]);
-          acc[a][2] = fmaf(p, v2, acc[a][2]); acc[a][3] = fmaf(p, v3, acc[a][3]);
+          acc[a][0] = fmaf(p, v4[0], acc[a][0]); acc[a][1] = fmaf(p, v4[1], acc[a][1]);
+          acc[a][2] = fmaf(p, v4[2], acc[a][2]); acc[a][3] = fmaf(p, v4[3], acc[a][3]);
         }
+    };
+    // four keys of the slice in flight (the loop is latency-bound: one small load per key); accumulated in key order
+    int j = sl;
+    for (; j + 3 * slices < Lk; j += 4 * slices) {
+      float va[4], vb[4], vc[4], vd[4];
+      loadv(j, va); loadv(j + slices, vb); loadv(j + 2 * slices, vc); loadv(j + 3 * slices, vd);
+      fma4(j, va); fma4(j + slices, vb); fma4(j + 2 * slices, vc); fma4(j + 3 * slices, vd);
+    }
+    for (; j < Lk; j += slices) {
+      float va[4];
+      loadv(j, va);
+      fma4(j, va);
     }
   }
   __syncthreads();                        // everyone is done reading the probabilities: reuse sm as [slices][nq][hd]
