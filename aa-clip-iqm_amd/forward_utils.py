@@ -7,7 +7,7 @@ from typing import Sequence
 import torch
 
 from aaclip_hip import engine
-from dataset.constants import CLASS_NAMES, DOMAINS, PROMPTS, REAL_NAMES
+from dataset.constants import CLASS_NAMES, DOMAINS, PROMPTS, REAL_NAMES  # noqa: F401  (DOMAINS: re-exported like the reference)
 from model.tokenizer import tokenize
 
 prompt_normal = PROMPTS["prompt_normal"]

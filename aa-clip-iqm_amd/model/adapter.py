@@ -11,14 +11,14 @@ its parameters are ordinary, seeded at construction and part of state_dict()
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 from torch import nn
 
 from aaclip_hip import engine
 
-from aaclip_hip._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, EPI_ACT_F32, EPI_BIAS
+from aaclip_hip._lib import ACT_LEAKY, ACT_RELU, EPI_ACT_F32, EPI_BIAS
 
 from .adapter_modules import SimpleAdapter, SimpleProj
 from .iqm import IQM, IQMOutput, sinusoidal_positions

@@ -12,7 +12,6 @@ from __future__ import annotations
 import json
 import logging
 import os
-import re
 from copy import deepcopy
 from pathlib import Path
 from typing import Optional, Tuple, Union

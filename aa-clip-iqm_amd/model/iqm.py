@@ -20,13 +20,13 @@ kernels of csrc/iqm.hip (aaclip_small_attention, aaclip_residual_layernorm, ...)
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence
+from typing import Optional
 
 import torch
 from torch import nn
 
-from aaclip_hip import _lib, engine
-from aaclip_hip._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, EPI_ACT_F32, EPI_BIAS, EPI_BIAS_GELU
+from aaclip_hip import engine
+from aaclip_hip._lib import EPI_ACT_F32, EPI_BIAS, EPI_BIAS_GELU
 
 
 class IQMOutput:

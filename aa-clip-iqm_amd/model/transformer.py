@@ -10,14 +10,12 @@ encode_text) never leave the batch-first layout.
 """
 from __future__ import annotations
 
-import math
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 from torch import nn
 
 from aaclip_hip import engine
-from aaclip_hip._lib import F32
 
 
 def to_2tuple(x):
