@@ -310,3 +310,47 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
         assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi}: spill in the K loop"
         checked += 1
     assert checked == 5
+
+
+def test_tower_run_plans_one_call_with_tap_buffers(monkeypatch):
+    """Host logic of Transformer.run (no GPU: engine.run_blocks is replaced by a recorder): the whole tower is ONE
+    aaclip_blocks_taps call with one output buffer per block; a tapped buffer is never written again (the block behind
+    it continues in a fresh one); adapters are handed to the call block by block; a change of attention mode
+    (DAPM_replace) splits the tower into one call per mode, the second reading what the first wrote last."""
+    from model.transformer import Transformer
+    calls = []
+
+    def fake_run_blocks(x, blocks, B, L, heads, code, causal=False, adapter_weights=None, mix=0.0, x_out=None,
+                        x_outs=None):
+        assert x_out is None and x_outs is not None and len(x_outs) == len(blocks)
+        calls.append({"src": x, "blocks": list(blocks), "outs": list(x_outs),
+                      "aws": list(adapter_weights) if adapter_weights is not None else None, "mix": mix})
+        for i, t in enumerate(x_outs):          # mark who wrote each buffer last
+            t.fill_(float(len(calls) * 100 + i))
+
+    monkeypatch.setattr(engine, "run_blocks", fake_run_blocks)
+    tr = Transformer(width=64, layers=6, heads=1, mlp_ratio=2.0)
+    x = torch.zeros(4, 64)
+    aws = [torch.zeros(1), torch.zeros(1), None, None, None, None]
+    final, taps = tr.run(x, 2, 2, _lib.F16, False, [2, 4, 6], adapter_weights=aws, mix=0.1)
+    assert len(calls) == 1 and calls[0]["src"] is x and calls[0]["aws"] == aws and calls[0]["mix"] == 0.1
+    outs = calls[0]["outs"]
+    assert outs[0] is x and outs[1] is x                      # blocks 1, 2 in place on the caller's buffer
+    assert outs[2] is outs[3] and outs[2] is not x            # behind the first tap: a fresh buffer
+    assert outs[4] is outs[5] and outs[4] is not outs[2] and outs[4] is not x
+    assert [t.data_ptr() for t in taps] == [x.data_ptr(), outs[2].data_ptr(), outs[4].data_ptr()]
+    assert final is outs[5] and final is taps[2]
+    # no taps: everything in place, one call
+    calls.clear()
+    final, taps = tr.run(torch.zeros(4, 64), 2, 2, _lib.F16, False)
+    assert len(calls) == 1 and taps == [] and all(t is calls[0]["src"] for t in calls[0]["outs"]) and final is calls[0]["src"]
+    # a mode change after block 4 (stage-1 "surgery" blocks): two calls; the second reads the first one's last buffer
+    calls.clear()
+    for blk in list(tr.resblocks)[4:]:
+        blk.surgery = True
+    x = torch.zeros(4, 64)
+    final, taps = tr.run(x, 2, 2, _lib.F16, False, [3])
+    assert [len(c["blocks"]) for c in calls] == [4, 2]
+    assert calls[0]["outs"][2] is x and calls[0]["outs"][3] is not x      # tap after block 3, block 4 in a fresh buffer
+    assert calls[1]["src"] is calls[0]["outs"][3] and all(t is calls[1]["src"] for t in calls[1]["outs"])
+    assert taps[0] is x and final is calls[1]["outs"][-1]
