@@ -262,7 +262,10 @@ def run_rank(args):
             key = "full_images_per_s" if args.workload == "tower" else "tower_images_per_s"
             extra[key] = round(2 * B / (time.perf_counter() - t1), 2)
             if args.precision != "fp32" and n_gpus == 1:
-                extra["fp32_companion"] = fp32_companion(build, args, B, dev, torch)
+                try:    # a secondary measurement must never cost the headline line (single rank: nothing to hang)
+                    extra["fp32_companion"] = fp32_companion(build, args, B, dev, torch)
+                except Exception as e:   # noqa: BLE001
+                    extra["fp32_companion"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if dist is not None:
             dist.barrier()
 
@@ -329,7 +332,10 @@ def run_rank(args):
             })
         result.update(extra)
         if n_gpus == 1 and not args.no_cpu_baseline and not rehearse:
-            result["cpu_baseline"] = cpu_baseline(cfg, args.workload)
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, args.workload)
+            except Exception as e:   # noqa: BLE001
+                result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:
