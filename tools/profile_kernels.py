@@ -28,8 +28,9 @@ if a.kernel == "attn":
     qkv[:, :D] *= 0.125 * 1.4426950408889634
     qkv = qkv.to(tdt)
     ctx = torch.empty(M, D, device=dev, dtype=tdt)
-    # aaclip_attention runs the natural-exp kernel; the block path pre-scales q by log2(e): same instruction count
-    run = lambda: _lib.check(lib.aaclip_attention(code, qkv.data_ptr(), ctx.data_ptr(), B, L, H, 0, st))
+    # the kernel variant the block path runs: q arrives in log2 units (the plain aaclip_attention contract applies the
+    # factor per score in fp32: 64 more VALU instructions per tile)
+    run = lambda: _lib.check(lib.aaclip_attention_log2q(code, qkv.data_ptr(), ctx.data_ptr(), B, L, H, 0, st))
 else:
     epi, N, K = {"qkv": (_lib.EPI_BIAS, 3072, 1024), "out_proj": (_lib.EPI_BIAS_RESID, 1024, 1024),
                  "c_fc": (_lib.EPI_BIAS_GELU, 4096, 1024), "c_proj": (_lib.EPI_BIAS_RESID, 1024, 4096)}[a.kernel]
