@@ -13,9 +13,10 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AACLIP_LIB") or os.path.join(_HERE, "libaaclip_hip.so")   # AACLIP_LIB: experiment builds
 MEASURE_LIB_PATH = os.path.join(_HERE, "libaaclip_hip_measure.so")   # `make measure`: A/B variants, ablations, stamps
-ABI_VERSION = 3   # include/aaclip.h AACLIP_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # include/aaclip.h AACLIP_ABI_VERSION this binding was written against
 
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, F16X2 = 0, 1, 2, 3   # F16X2: split fp16 (hi + lo pairs), include/aaclip.h
+EXACT16_QKV, EXACT16_OUT, EXACT16_FC, EXACT16_PROJ, EXACT16_ADAPTER = 1, 2, 4, 8, 16
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_ACT_F32 = 0, 1, 2, 3
 
@@ -28,7 +29,7 @@ class BlockWeights(C.Structure):
     _fields_ = [("struct_bytes", _sz)] + [(n, _vp) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b",
         "fc_w", "fc_b", "proj_w", "proj_b", "adapter_w", "fc_w_fold", "fc_fold_s", "fc_fold_b",
-        "qkv_w_fold", "qkv_fold_s", "qkv_fold_b")]
+        "qkv_w_fold", "qkv_fold_s", "qkv_fold_b")] + [("exact16", C.c_uint)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)

@@ -21,11 +21,13 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, F16, F32, BlockWeights
+from ._lib import BF16, F16, F16X2, F32, BlockWeights
 
-_TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
+_TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16, F16X2: torch.float16}
+# "fp16x2": split fp16 (every matrix-product operand as an fp16 hi + lo pair, 3 MFMA products per matrix product):
+# the 16-bit-MFMA mode whose taps and anomaly maps stay inside 1e-3 abs + 1e-2 rel of the fp32 reference
 _PRECISION = {"fp32": F32, "f32": F32, "fp16": F16, "f16": F16, "bf16": BF16, "amp": F16, "pure_fp16": F16,
-              "pure_bf16": BF16, "amp_bf16": BF16}
+              "pure_bf16": BF16, "amp_bf16": BF16, "fp16x2": F16X2, "f16x2": F16X2, "split": F16X2}
 
 
 def dtype_code(precision) -> int:
@@ -40,11 +42,25 @@ def dtype_code(precision) -> int:
     try:
         return _PRECISION[str(precision).lower()]
     except KeyError:
-        raise ValueError(f"unknown precision {precision!r}; use fp32, fp16 or bf16")
+        raise ValueError(f"unknown precision {precision!r}; use fp32, fp16x2, fp16 or bf16")
 
 
 def torch_dtype(code: int) -> torch.dtype:
     return _TORCH_DT[code]
+
+
+def plain_code(code: int) -> int:
+    """The arithmetic type of the side paths that have no split-fp16 kernels (IQM branch): exact fp32 there."""
+    return F32 if code == F16X2 else code
+
+
+def split_rows(t: torch.Tensor) -> torch.Tensor:
+    """fp32 [R, C] -> split fp16 [R, 2C]: hi = fp16(v) | lo = fp16(v - hi) (include/aaclip.h, AACLIP_F16X2).
+    Load-time / caller-side operand preparation, like the .to(dtype) of the other modes."""
+    v = t.detach().float()
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo], dim=-1).contiguous()
 
 
 def _stream(dev: torch.device) -> int:
@@ -102,11 +118,16 @@ class WeightCache:
         self._c: Dict[Tuple[int, int, str], tuple] = {}
 
     def get(self, p: torch.Tensor, code: int, kind: str = "plain") -> torch.Tensor:
+        """kind: 'plain' | 'transpose' | 'conv'; with a '+exact' suffix and code F16X2 the result is the plain fp16
+        weight [out, in] when every value is exact in fp16 (lo half all zero), else the split [out, 2*in] one --
+        tell them apart by the shape."""
         key = (id(p), code, kind)
         hit = self._c.get(key)
         if hit is not None and hit[0]() is p and hit[1] == p.data_ptr() and hit[2] == p._version:
             return hit[3]
         src = p.detach()
+        allow_exact = kind.endswith("+exact")
+        kind = kind.split("+")[0]
         if kind == "transpose":          # [in, out] parameter used as x @ P  ->  [out, in]
             src = src.t()
         elif kind == "conv":             # conv1.weight [D,3,ps,ps] -> [D, Kpad]
@@ -116,7 +137,12 @@ class WeightCache:
             pad = torch.zeros(d, kpad, dtype=flat.dtype, device=flat.device)
             pad[:, : flat.shape[1]] = flat
             src = pad
-        out = src.to(_TORCH_DT[code]).contiguous()
+        if code == F16X2:
+            out = split_rows(src)
+            if allow_exact and not bool(out[:, src.shape[1]:].any()):
+                out = out[:, : src.shape[1]].contiguous()
+        else:
+            out = src.to(_TORCH_DT[code]).contiguous()
         cache = self._c
 
         def _drop(_ref, key=key):
@@ -181,18 +207,31 @@ def pack_block(block, code: int, adapter_weight: Optional[torch.Tensor]) -> Tupl
     w = BlockWeights()
     w.ln1_w = _keep(refs, _f32c(block.ln_1.weight))
     w.ln1_b = _keep(refs, _f32c(block.ln_1.bias))
-    w.qkv_w = _keep(refs, CACHE.get(block.attn.in_proj_weight, code))
+    ex = 0
+
+    def mat(param, bit):
+        """matrix weight in the compute dtype; split fp16: plain fp16 + its exact16 bit when the lo half is zero"""
+        nonlocal ex
+        if code != F16X2:
+            return _keep(refs, CACHE.get(param, code))
+        t = CACHE.get(param, code, "plain+exact")
+        if t.shape[1] == param.shape[1]:
+            ex |= bit
+        return _keep(refs, t)
+
+    w.qkv_w = mat(block.attn.in_proj_weight, _lib.EXACT16_QKV)
     w.qkv_b = _keep(refs, _f32c(block.attn.in_proj_bias))
-    w.out_w = _keep(refs, CACHE.get(block.attn.out_proj.weight, code))
+    w.out_w = mat(block.attn.out_proj.weight, _lib.EXACT16_OUT)
     w.out_b = _keep(refs, _f32c(block.attn.out_proj.bias))
     w.ln2_w = _keep(refs, _f32c(block.ln_2.weight))
     w.ln2_b = _keep(refs, _f32c(block.ln_2.bias))
-    w.fc_w = _keep(refs, CACHE.get(block.mlp.c_fc.weight, code))
+    w.fc_w = mat(block.mlp.c_fc.weight, _lib.EXACT16_FC)
     w.fc_b = _keep(refs, _f32c(block.mlp.c_fc.bias))
-    w.proj_w = _keep(refs, CACHE.get(block.mlp.c_proj.weight, code))
+    w.proj_w = mat(block.mlp.c_proj.weight, _lib.EXACT16_PROJ)
     w.proj_b = _keep(refs, _f32c(block.mlp.c_proj.bias))
-    w.adapter_w = _keep(refs, CACHE.get(adapter_weight, code)) if adapter_weight is not None else None
-    if code != F32:
+    w.adapter_w = mat(adapter_weight, _lib.EXACT16_ADAPTER) if adapter_weight is not None else None
+    w.exact16 = ex
+    if code in (F16, BF16):
         wf, fs, fb, qf, qs, qb = FOLDS.get(block, code)
         w.fc_w_fold, w.fc_fold_s, w.fc_fold_b = _keep(refs, wf), _keep(refs, fs), _keep(refs, fb)
         w.qkv_w_fold, w.qkv_fold_s, w.qkv_fold_b = _keep(refs, qf), _keep(refs, qs), _keep(refs, qb)
@@ -368,7 +407,8 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     xc = _f32c(x)
     D = xc.shape[-1]
     rows = xc.numel() // D
-    out = torch.empty(xc.shape, dtype=_TORCH_DT[out_code], device=x.device)
+    oshape = xc.shape if out_code != F16X2 else (*xc.shape[:-1], 2 * D)   # split rows: [hi D | lo D]
+    out = torch.empty(oshape, dtype=_TORCH_DT[out_code], device=x.device)
     w, b = _f32c(weight), _f32c(bias)
     _lib.check(lib.aaclip_layernorm(xc.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), out_code, rows, D,
                                     float(eps), _stream(x.device)), "layernorm")
@@ -384,10 +424,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     K = x.shape[-1]
     w = CACHE.get(weight, code, kind)
     N = w.shape[0]
-    a = x.detach().reshape(-1, K).to(_TORCH_DT[code]).contiguous()
+    a = x.detach().reshape(-1, K)
+    a = split_rows(a) if code == F16X2 else a.to(_TORCH_DT[code]).contiguous()
     out = torch.empty(a.shape[0], N, dtype=torch.float32, device=x.device)
     b = _f32c(bias) if bias is not None else None
-    _lib.check(lib.aaclip_gemm(code, _lib.EPI_ACT_F32, a.data_ptr(), K, w.data_ptr(), _ptr(b), out.data_ptr(), N,
+    _lib.check(lib.aaclip_gemm(code, _lib.EPI_ACT_F32, a.data_ptr(), a.shape[1], w.data_ptr(), _ptr(b), out.data_ptr(), N,
                                a.shape[0], N, K, int(act), 0, 1.0, _stream(x.device)), "gemm")
     return out.reshape(*x.shape[:-1], N)
 
@@ -501,10 +542,11 @@ def gemm(code: int, epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[t
          act: int = 0) -> torch.Tensor:
     """aaclip_gemm on prepared operands: a [M, K] and w [N, K] in the compute dtype, bias fp32 [N] or None,
     out [M, N] (16-bit for EPI_BIAS / EPI_BIAS_GELU, fp32 for EPI_ACT_F32)."""
-    M, K = a.shape
+    M, lda = a.shape
     N = w.shape[0]
-    _lib.check(_lib.load().aaclip_gemm(code, epi, a.data_ptr(), K, w.data_ptr(), _ptr(bias), out.data_ptr(), N, M, N, K,
-                                       int(act), 0, 1.0, _stream(a.device)), "gemm")
+    K = lda // 2 if code == F16X2 else lda          # split rows: [hi K | lo K]
+    _lib.check(_lib.load().aaclip_gemm(code, epi, a.data_ptr(), lda, w.data_ptr(), _ptr(bias), out.data_ptr(),
+                                       out.shape[1], M, N, K, int(act), 0, 1.0, _stream(a.device)), "gemm")
     return out
 
 

@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
     const bool first = kt == 0;
     if (first || __any(mt > 0.f)) {
       const float delta = first ? mt : fmaxf(mt, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      // tile 0: l and o are still zero and must stay so -- exp2(-mt) overflows to +inf when every score of the
+      // tile is below about -128 (log2 units), and 0 * inf would make the whole row NaN
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
       m2 += delta;
       l *= alpha;
 #pragma unroll
@@ -232,6 +234,212 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = from_float<T>(o[db][4 * gi + j] * inv);
         *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Split-fp16 variant (AACLIP_F16X2, common.h): q, k, v arrive as hi + lo fp16 pairs (rows [hi 3D | lo 3D]), the
+// context leaves the same way (rows [hi D | lo D]).  Same structure as attn16_kernel; per 64-key tile a wave issues
+//   S^T = Kh.Qh^T + Kl.Qh^T + Kh.Ql^T   (24 MFMAs: scores carry ~21 bits of q and k)
+//   O^T += Vh^T.P^T + Vl^T.P^T           (16 MFMAs: P is rounded to fp16 once, v keeps its lo half)
+// Stage image: [Kh 8K][Vh 8K][Kl 8K][Vl 8K], two stages, two workgroups per CU.
+template <bool LOG2Q>
+__global__ __launch_bounds__(256, 2) void attn16s_kernel(const f16* __restrict__ qkv, f16* __restrict__ ctx, int L, int H,
+                                                         int causal) {
+  typedef f16x8 vec8;
+  typedef f16x4 vec4;
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) char smem[65536];
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int D = H * 64;
+  const long ld = 6L * D;      // split row: [q k v hi | q k v lo]
+  const int LO = 3 * D;
+  const f16* base = qkv + (long)b * L * ld + head * 64;
+  const int q0 = qt * 128 + wave * 32;
+  const int qi = q0 + r;
+  const int qrow = qi < L ? qi : L - 1;
+
+  vec8 qh[4], ql[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qh[ks] = *(const vec8*)(base + (long)qrow * ld + 16 * ks + 8 * h);
+    ql[ks] = *(const vec8*)(base + (long)qrow * ld + LO + 16 * ks + 8 * h);
+  }
+
+  const f16* ksrc[2];
+  const f16* vsrc[2];
+  int drow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pslot = (wave * 2 + j) * 64 + lane;
+    const int row = pslot >> 3, sl = pslot & 7;
+    drow[j] = row;
+    ksrc[j] = base + (long)row * ld + D + (sl ^ xk(row)) * 8;
+    vsrc[j] = base + (long)row * ld + 2 * D + (sl ^ xv(row)) * 8;
+  }
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ xk(r)) << 4);
+  int voff[2];
+  {
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+    const int row = 4 * (g >> 1) + qq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
+      voff[db] = 8192 + row * 128 + ((chunk ^ xv(row)) << 4) + (pp & 1) * 8;
+    }
+  }
+
+  int last_q = qt * 128 + 127;
+  if (last_q > L - 1) last_q = L - 1;
+  const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
+
+  auto stage = [&](int st, int kt) {
+    char* dst = smem + st * 32768 + wave * 2048;
+    const long step = (long)kt * 64 * ld;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int over = kt * 64 + drow[j] - (L - 1);
+      over = over > 0 ? over : 0;   // rows past the end re-read row L-1 (masked later)
+      const long so = step - (long)over * ld;
+      glds16(ksrc[j] + so, dst + j * 1024);
+      glds16(vsrc[j] + so, dst + 8192 + j * 1024);
+      glds16(ksrc[j] + so + LO, dst + 16384 + j * 1024);
+      glds16(vsrc[j] + so + LO, dst + 24576 + j * 1024);
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float m2 = 0.f, l = 0.f;
+
+  auto tile = [&](const char* sb, int kt) {
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[sub][e] = LOG2Q ? -m2 : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const vec8 ah = *(const vec8*)(sb + koff[ks] + sub * 4096);
+        const vec8 al = *(const vec8*)(sb + 16384 + koff[ks] + sub * 4096);
+        s[sub] = Elem<f16>::mma32(al, qh[ks], s[sub]);
+        s[sub] = Elem<f16>::mma32(ah, ql[ks], s[sub]);
+        s[sub] = Elem<f16>::mma32(ah, qh[ks], s[sub]);
+      }
+      if (!LOG2Q) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = fmaf(s[sub][e], LOG2E, -m2);
+      }
+    }
+    const int k0 = kt * 64;
+    const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));
+    if (need_mask) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int key = k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          bool dead = (key >= L) || (causal && key > qi);
+          s[sub][e] = dead ? -INFINITY : s[sub][e];
+        }
+    }
+    float mt = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s[sub][e]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const bool first = kt == 0;
+    if (first || __any(mt > 0.f)) {
+      const float delta = first ? mt : fmaxf(mt, 0.f);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // tile 0: l and o are still zero
+      m2 += delta;
+      l *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pv = __builtin_amdgcn_exp2f(s[sub][e]);
+        s[sub][e] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l += rs;
+
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        vec8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (f16)s[sub][8 * s2 + j];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
+#pragma unroll
+          for (int part = 0; part < 2; ++part) {   // Vh, then Vl (16 KiB further)
+            i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + part * 16384));
+            i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + part * 16384 + 8 * 128));
+            i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[db] = Elem<f16>::mma32(__builtin_bit_cast(vec8, both), pf, o[db]);
+          }
+        }
+      }
+  };
+
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 1 < nkt) stage(1, kt + 1);
+    tile(smem, kt);
+    wait_vm0();
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    if (kt + 2 < nkt) stage(0, kt + 2);
+    tile(smem + 32768, kt + 1);
+    wait_vm0();
+    __syncthreads();
+  }
+
+  if (qi < L) {
+    const float inv = 1.0f / l;
+    f16* dst = ctx + ((long)b * L + qi) * 2 * D + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        vec4 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f16 a, c;
+          split16(o[db][4 * gi + j] * inv, a, c);
+          vh[j] = a;
+          vl[j] = c;
+        }
+        *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = vh;
+        *(vec4*)(dst + D + db * 32 + 8 * gi + 4 * h) = vl;
       }
   }
 }
@@ -498,7 +706,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn16x2_kernel(const T* __restric
       // far is masked (-inf) keeps m where it is.
       float delta = first ? mt : fmaxf(mt, 0.f);
       delta = delta == -INFINITY ? 0.f : delta;
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      // very first sub-tile: l and O are still zero and must stay so (exp2(-mt) is +inf when every score of the
+      // sub-tile is below about -128 in log2 units, and 0 * inf = NaN for the whole row)
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
       m2[qb] += delta;
       l[qb] *= alpha;
       if (pend) pend[qb] *= alpha;
@@ -985,7 +1195,7 @@ AACLIP_DEV void attn16u_body(char* smem, const T* __restrict__ qkv, T* __restric
     const float mt = xhalf_max(a);
     float delta = (kt == 0 && sub == 0) ? mt : fmaxf(mt, 0.f);   // very first unit: m = its maximum; later m only grows
     delta = delta == -INFINITY ? 0.f : delta;                     // every key so far masked: m stays
-    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    const float alpha = (kt == 0 && sub == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);   // l, O still zero: no 0 * inf
     m2[qb] += delta;
     ll[qb] *= alpha;
 #pragma unroll
@@ -1397,7 +1607,7 @@ __global__ __launch_bounds__(256, 2) void attn16p_kernel(const T* __restrict__ q
   auto rebase = [&](f32x16 (&s)[2], float mt, bool first) {
     if (first || __any(mt > 0.f)) {
       const float delta = first ? mt : fmaxf(mt, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // l, O still zero: no 0 * inf
       m2 += delta;
       l *= alpha;
 #pragma unroll
@@ -1757,7 +1967,11 @@ bool set_attn_variant(int v) {
 
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
                       hipStream_t s) {
-  if (dtype == AACLIP_F32 && L >= 64 && g_attn_variant != 1) {   // fp32 MFMA kernel (32 queries per wave)
+  if (dtype == AACLIP_F16X2) {   // split fp16 rows in, split fp16 rows out
+    dim3 g((L + 127) / 128, H, B);
+    if (log2q) hipLaunchKernelGGL((attn16s_kernel<true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    else hipLaunchKernelGGL((attn16s_kernel<false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+  } else if (dtype == AACLIP_F32 && L >= 64 && g_attn_variant != 1) {   // fp32 MFMA kernel (32 queries per wave)
     dim3 g((L + 127) / 128, H, B);
     hipLaunchKernelGGL(attn32m_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);
   } else if (dtype == AACLIP_F32) {                               // short sequences: one query per lane on the VALU

@@ -58,13 +58,16 @@ struct ProfScope {
   }
 };
 
-static inline size_t esize(int dtype) { return dtype == AACLIP_F32 ? 4 : 2; }
+// bytes per element of an activation / weight row in the compute dtype (a split fp16 value is a hi and a lo half)
+static inline size_t esize(int dtype) { return (dtype == AACLIP_F32 || dtype == AACLIP_F16X2) ? 4 : 2; }
+static inline int split_w(int dtype) { return dtype == AACLIP_F16X2 ? 2 : 1; }   // row stride factor of split rows
 static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 // aux region of the workspace: 16-bit copy of the residual rows, per-row partial sums [rows][D/64][2], (a, b) pairs
 static inline size_t aux_bytes(size_t es, long rows, int D) {
   return up256((size_t)rows * D * es) + up256((size_t)rows * (D / 64 + 1) * 2 * 4) + up256((size_t)rows * 2 * 4);
 }
-static inline bool dtype_ok(int d) { return d == AACLIP_F32 || d == AACLIP_F16 || d == AACLIP_BF16; }
+static inline bool dtype_ok(int d) { return d == AACLIP_F32 || d == AACLIP_F16 || d == AACLIP_BF16 || d == AACLIP_F16X2; }
+static inline bool plain_dtype_ok(int d) { return d == AACLIP_F32 || d == AACLIP_F16 || d == AACLIP_BF16; }
 
 extern "C" {
 
@@ -212,7 +215,7 @@ int aaclip_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H,
 }
 
 int aaclip_attention_log2q(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, void* stream) {
-  REQUIRE(dtype == AACLIP_F16 || dtype == AACLIP_BF16, "attention_log2q: 16-bit dtypes only");
+  REQUIRE(dtype == AACLIP_F16 || dtype == AACLIP_BF16 || dtype == AACLIP_F16X2, "attention_log2q: 16-bit dtypes only");
   REQUIRE(qkv && ctx, "attention: null pointer");
   REQUIRE(B > 0 && L > 0 && H > 0, "attention: empty problem");
   REQUIRE(B <= 65535 && H <= 65535, "attention: grid limit");
@@ -232,7 +235,7 @@ int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight,
 
 int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
                            int H, int hd, float scale, void* stream) {
-  REQUIRE(dtype_ok(kv_dtype), "small_attention: bad dtype");
+  REQUIRE(plain_dtype_ok(kv_dtype), "small_attention: bad dtype (fp32, fp16 or bf16)");
   REQUIRE(q && k && v && out, "small_attention: null pointer");
   REQUIRE(B > 0 && B <= 65535 && H <= 65535, "small_attention: bad batch / heads");
   const char* m = small_attention_check(nq, Lk, H, hd);
@@ -258,7 +261,7 @@ int aaclip_combine3(const float* a, const float* b, const float* c, float wa, fl
 
 int aaclip_linear_smallk(int out_dtype, const float* x, const float* W, const float* bias, void* y, long R, int N, int K,
                          void* stream) {
-  REQUIRE(dtype_ok(out_dtype), "linear_smallk: bad dtype");
+  REQUIRE(plain_dtype_ok(out_dtype), "linear_smallk: bad dtype (fp32, fp16 or bf16)");
   REQUIRE(x && W && y, "linear_smallk: null pointer");
   REQUIRE(R > 0 && N > 0 && K >= 1 && K <= 4, "linear_smallk: in_features must be 1..4");
   launch_linear_smallk(out_dtype, x, W, bias, y, R, N, K, (hipStream_t)stream);
@@ -267,7 +270,7 @@ int aaclip_linear_smallk(int out_dtype, const float* x, const float* W, const fl
 
 int aaclip_drop_cls_rows(int dtype, const void* src, void* dst, int B, int L, int E, int rows_per_image, int row_off,
                          void* stream) {
-  REQUIRE(dtype_ok(dtype), "drop_cls_rows: bad dtype");
+  REQUIRE(plain_dtype_ok(dtype), "drop_cls_rows: bad dtype (fp32, fp16 or bf16)");
   REQUIRE(src && dst, "drop_cls_rows: null pointer");
   REQUIRE(B > 0 && L > 1 && E > 0 && E % 8 == 0, "drop_cls_rows: E must be a multiple of 8");
   REQUIRE(row_off >= 0 && row_off + (L - 1) <= rows_per_image, "drop_cls_rows: rows do not fit the destination");
@@ -310,7 +313,7 @@ int aaclip_patch_embed(const float* img, const void* conv_w, const float* cls, c
   launch_im2col(dtype, img, ws, B, 3, H, W, ps, Kpad, s);
   GemmParams p;
   memset(&p, 0, sizeof(p));
-  p.A = ws; p.lda = Kpad; p.W = conv_w; p.M = B * P; p.N = D; p.K = Kpad; p.out = x; p.ldc = D;
+  p.A = ws; p.lda = split_w(dtype) * Kpad; p.W = conv_w; p.M = B * P; p.N = D; p.K = Kpad; p.out = x; p.ldc = D;
   p.pos = pos; p.P = P; p.L = L;
   m = gemm_check(dtype, EPI_PATCH, p);
   if (m) return fail(-1, m);
@@ -342,7 +345,9 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
   float* partials = (float*)(aux + up256((size_t)rows * D * es));
   float* rowab = (float*)((char*)partials + up256((size_t)rows * (D / 64 + 1) * 2 * 4));
   const int M = (int)rows;
-  const bool folding = g_ln_fold && dtype != AACLIP_F32;
+  const bool folding = g_ln_fold && (dtype == AACLIP_F16 || dtype == AACLIP_BF16);
+  const int sw = split_w(dtype);                    // split fp16 rows are [hi | lo]: twice the row stride
+  const unsigned ex = dtype == AACLIP_F16X2 ? w->exact16 : 0u;   // weights whose lo half is all zero
 
   GemmParams p;
   // ---- x += out_proj(attn(ln_1 x))
@@ -355,8 +360,10 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     { ProfScope ps(0, s); launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
     // only the value third of in_proj is needed; v lives behind the packed q|k|v buffer inside `big`
     char* vbuf = big + (size_t)rows * 3 * D * es;
-    p.A = narrow; p.lda = D; p.W = (const char*)w->qkv_w + (size_t)2 * D * D * es; p.M = M; p.N = D; p.K = D;
-    p.bias = w->qkv_b + 2 * D; p.out = vbuf; p.ldc = D;
+    p.A = narrow; p.lda = sw * D; p.M = M; p.N = D; p.K = D;
+    p.w_exact16 = ex & AACLIP_EXACT16_QKV;
+    p.W = (const char*)w->qkv_w + (size_t)2 * D * D * (p.w_exact16 ? 2 : es);
+    p.bias = w->qkv_b + 2 * D; p.out = vbuf; p.ldc = sw * D;
     { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
     {
       ProfScope ps(2, s);
@@ -366,8 +373,8 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     }
     ctx = vbuf;
   } else {
-    p.A = narrow; p.lda = D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
-    p.ldc = 3 * D; p.scale_cols = D; p.scale = qscale;
+    p.A = narrow; p.lda = sw * D; p.W = w->qkv_w; p.M = M; p.N = 3 * D; p.K = D; p.bias = w->qkv_b; p.out = big;
+    p.ldc = sw * 3 * D; p.scale_cols = D; p.scale = qscale; p.w_exact16 = ex & AACLIP_EXACT16_QKV;
     if (aux_in && folding && w->qkv_w_fold && w->qkv_fold_s && w->qkv_fold_b && gemm_routes_to_256t(dtype, p)) {
       // ln_1 folded into the QKV product (include/aaclip.h, aaclip_block_weights)
       p.A = x16; p.W = w->qkv_w_fold; p.bias = w->qkv_fold_b; p.row_ab = rowab; p.col_s = w->qkv_fold_s;
@@ -379,14 +386,15 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s); }
   }
   memset(&p, 0, sizeof(p));
-  p.A = ctx; p.lda = D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
+  p.A = ctx; p.lda = sw * D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
+  p.w_exact16 = ex & AACLIP_EXACT16_OUT;
   if (x_in != x) p.resid = x_in;
   // ln_2 folded into c_fc: only where both products run on the kernels whose epilogue implements it;
   // everywhere else the ln_2 pass runs as before
   GemmParams fc;
   memset(&fc, 0, sizeof(fc));
-  fc.lda = D; fc.M = M; fc.N = F; fc.K = D; fc.out = big; fc.ldc = F;
-  fc.A = narrow; fc.W = w->fc_w; fc.bias = w->fc_b;
+  fc.lda = sw * D; fc.M = M; fc.N = F; fc.K = D; fc.out = big; fc.ldc = sw * F;
+  fc.A = narrow; fc.W = w->fc_w; fc.bias = w->fc_b; fc.w_exact16 = ex & AACLIP_EXACT16_FC;
   const bool fold2 = folding && w->fc_w_fold && w->fc_fold_s && w->fc_fold_b && gemm_routes_to_256t(dtype, p) &&
                      gemm_routes_to_256t(dtype, fc);
   if (fold2) {
@@ -405,7 +413,8 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
   }
   { ProfScope ps(4, s); launch_gemm(dtype, EPI_BIAS_GELU, fc, s); }
   memset(&p, 0, sizeof(p));
-  p.A = big; p.lda = F; p.W = w->proj_w; p.M = M; p.N = D; p.K = F; p.bias = w->proj_b; p.out = x; p.ldc = D;
+  p.A = big; p.lda = sw * F; p.W = w->proj_w; p.M = M; p.N = D; p.K = F; p.bias = w->proj_b; p.out = x; p.ldc = D;
+  p.w_exact16 = ex & AACLIP_EXACT16_PROJ;
   // the c_proj epilogue can also emit the new rows in 16 bits: input of the adapter product, or (with their
   // row sums) of the next block's folded ln_1
   const bool emit = folding && gemm_routes_to_256t(dtype, p) && (w->adapter_w || want_out);
@@ -425,12 +434,16 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     const void* a_in = x;
     if (emit) {
       a_in = x16;
+    } else if (dtype == AACLIP_F16X2) {
+      launch_split_rows(x, narrow, rows, D, s);
+      a_in = narrow;
     } else if (dtype != AACLIP_F32) {
       launch_cast_rows(dtype, x, narrow, rows * D, s);
       a_in = narrow;
     }
     memset(&p, 0, sizeof(p));
-    p.A = a_in; p.lda = D; p.W = w->adapter_w; p.M = M; p.N = D; p.K = D; p.out = big; p.ldc = D; p.act = 1;
+    p.A = a_in; p.lda = sw * D; p.W = w->adapter_w; p.M = M; p.N = D; p.K = D; p.out = big; p.ldc = D; p.act = 1;
+    p.w_exact16 = ex & AACLIP_EXACT16_ADAPTER;
     launch_gemm(dtype, EPI_ACT_F32, p, s);
     if (folding && want_out) {
       launch_adapter_mix_fold(dtype, x, (const float*)big, rows, D, mix, x16, rowab, s);
@@ -546,7 +559,7 @@ int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post
   launch_layernorm(dtype, x, ln_post_w, ln_post_b, narrow, rows, D, 1e-5f, s);
   GemmParams p;
   memset(&p, 0, sizeof(p));
-  p.A = narrow; p.lda = D; p.W = proj_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
+  p.A = narrow; p.lda = split_w(dtype) * D; p.W = proj_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
   launch_gemm(dtype, EPI_ACT_F32, p, s);
   launch_normalize_rows((const float*)big, seg_out, B, L, 1, E, s);
   if (det_w) {
@@ -568,7 +581,7 @@ int aaclip_det_head(const float* x, const float* ln_post_w, const float* ln_post
   launch_layernorm(dtype, x, ln_post_w, ln_post_b, narrow, rows, D, 1e-5f, s);
   GemmParams p;
   memset(&p, 0, sizeof(p));
-  p.A = narrow; p.lda = D; p.W = det_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
+  p.A = narrow; p.lda = split_w(dtype) * D; p.W = det_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
   launch_gemm(dtype, EPI_ACT_F32, p, s);
   launch_det_mean((const float*)big, (float*)narrow, (size_t)(big - narrow) / 4, det_out, B, L, 1, E, s);
   return finish("det_head");
@@ -677,7 +690,7 @@ int aaclip_row_head(const float* x, const int32_t* tokens, const float* ln_w, co
   launch_gather_rows(dtype, ln_out, picked, tokens, n, T, D, mode, s);
   GemmParams p;
   memset(&p, 0, sizeof(p));
-  p.A = picked; p.lda = D; p.W = proj_w; p.M = n; p.N = E; p.K = D; p.out = out; p.ldc = E; p.act = act;
+  p.A = picked; p.lda = split_w(dtype) * D; p.W = proj_w; p.M = n; p.N = E; p.K = D; p.out = out; p.ldc = E; p.act = act;
   const char* gm = gemm_check(dtype, EPI_ACT_F32, p);
   if (gm) return fail(-1, gm);
   launch_gemm(dtype, EPI_ACT_F32, p, s);

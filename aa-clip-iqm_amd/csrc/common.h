@@ -40,6 +40,47 @@ template <> struct Elem<bf16> {
 template <typename T> AACLIP_DEV T from_float(float v) { return (T)v; }
 template <typename T> AACLIP_DEV float to_float(T v) { return (float)v; }
 
+// ------------------------------------------------------------ split fp16 (AACLIP_F16X2)
+// A value v is carried as two fp16 numbers hi = fp16(v), lo = fp16(v - hi): 21-22 significant bits for the values
+// this path sees (|v| well inside fp16's normal range; lo goes subnormal below |v| ~ 2^-3 and then still resolves
+// 2^-24 absolute).  A split row of width C is stored as C hi values followed by C lo values (row stride >= 2C
+// halves), so a product over K becomes a product over "virtual" K tiles: for K tile j the kernels accumulate
+// Ah_j.Wh_j + Al_j.Wh_j + Ah_j.Wl_j into the same fp32 accumulator (the Al.Wl term, 2^-22 relative, is dropped).
+AACLIP_DEV void split16(float v, f16& hi, f16& lo) {
+  hi = (f16)v;
+  lo = (f16)(v - (float)hi);
+}
+// virtual K tile t of a split product -> byte offsets (from the hi plane's start) of its A and W tiles;
+// K2 = bytes from a row's hi plane to its lo plane (2*K for a [.., 2K] split row).  NP = 3: both operands split;
+// NP = 2: W has no lo plane (its values are exact in fp16), products Ah.W + Al.W only.
+template <int NP> AACLIP_DEV int split_off_a(int t, int K2) {   // NP = 0: plain operands, tile t at t * 128 bytes
+  if (NP == 0) return t * 128;
+  if (NP == 3) {
+    const int j = (int)(((unsigned)t * 43691u) >> 17);
+    return j * 128 + (t - 3 * j == 1 ? K2 : 0);
+  }
+  return (t >> 1) * 128 + ((t & 1) ? K2 : 0);
+}
+template <int NP> AACLIP_DEV int split_off_w(int t, int K2) {
+  if (NP == 0) return t * 128;
+  if (NP == 3) {
+    const int j = (int)(((unsigned)t * 43691u) >> 17);
+    return j * 128 + (t - 3 * j == 2 ? K2 : 0);
+  }
+  return (t >> 1) * 128;
+}
+template <int NP> AACLIP_DEV void split_tile_off(int t, int K2, int& offA, int& offW) {
+  if (NP == 3) {
+    const int j = (int)(((unsigned)t * 43691u) >> 17);   // t / 3 for t < 98304
+    const int r = t - 3 * j;
+    offA = j * 128 + (r == 1 ? K2 : 0);
+    offW = j * 128 + (r == 2 ? K2 : 0);
+  } else {
+    offA = (t >> 1) * 128 + ((t & 1) ? K2 : 0);
+    offW = (t >> 1) * 128;
+  }
+}
+
 // ------------------------------------------------------------ wave reductions
 AACLIP_DEV float wave_sum(float v) {
 #pragma unroll

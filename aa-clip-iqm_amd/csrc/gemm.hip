@@ -20,17 +20,31 @@
 
 namespace aaclip {
 
-template <int EPI, typename TOut>
+template <typename TOut, bool SPLIT>
+AACLIP_DEV void store16(const GemmParams& p, int row, int col, float v) {
+  if (SPLIT) {   // split fp16 row: hi plane, then the lo plane N columns further
+    f16 hi, lo;
+    split16(v, hi, lo);
+    f16* o = (f16*)p.out + (long)row * p.ldc + col;
+    o[0] = hi;
+    o[p.N] = lo;
+  } else {
+    ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
+  }
+}
+
+template <int EPI, typename TOut, bool SPLIT = false>
 AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
   if (EPI == EPI_BIAS) {
     v += p.bias[col];
     if (col < p.scale_cols) v *= p.scale;
-    ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
+    store16<TOut, SPLIT>(p, row, col, v);
   } else if (EPI == EPI_BIAS_GELU) {
     // 16-bit outputs: the polynomial erf of common.h (error far below the output rounding), same in every 16-bit kernel so that
-    // results do not depend on which tile size a batch selects; fp32 keeps erff
+    // results do not depend on which tile size a batch selects (split fp16 included: the polynomial's 1.2e-5 is 40x
+    // below one fp16 rounding); fp32 keeps erff
     v = sizeof(TOut) == 4 ? gelu_erf(v + p.bias[col]) : gelu_fast(v + p.bias[col]);
-    ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
+    store16<TOut, SPLIT>(p, row, col, v);
   } else if (EPI == EPI_BIAS_RESID) {
     float* x = (float*)p.out + (long)row * p.ldc + col;
     const float r = p.resid ? p.resid[(long)row * p.ldc + col] : *x;
@@ -48,7 +62,9 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
 }
 
 // ------------------------------------------------------------------ 16-bit
-template <typename T, int EPI>
+// NP = 0: plain 16-bit operands.  NP = 3 / 2 (T = f16): split fp16 operands (common.h), the K loop walks 3 (2)
+// virtual tiles per K tile.
+template <typename T, int EPI, int NP = 0>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[65536];  // 2 stages x (A 16K + W 16K)
@@ -71,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     int ar = tm * 128 + row;
     ar = ar < p.M ? ar : p.M - 1;
     asrc[j] = (const T*)p.A + (long)ar * p.lda + chunk * 8;
-    wsrc[j] = (const T*)p.W + (long)(tn * 128 + row) * p.K + chunk * 8;
+    wsrc[j] = (const T*)p.W + (long)(tn * 128 + row) * (NP == 3 ? 2 * p.K : p.K) + chunk * 8;
   }
   // --- fragment read offsets inside a tile
   int aoff[2][4], boff[2][4];
@@ -91,13 +107,19 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = p.K >> 6;
+  const int nk = (p.K >> 6) * (NP ? NP : 1);
   auto stage = [&](int s, int kt) {
     char* base = smem + s * 32768 + wave * 4096;
+    int oa = kt * 64, ow = kt * 64;   // element offsets of this (virtual) K tile
+    if (NP) {
+      split_tile_off<NP ? NP : 3>(kt, 2 * p.K, oa, ow);
+      oa >>= 1;
+      ow >>= 1;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      glds16(asrc[j] + kt * 64, base + j * 1024);
-      glds16(wsrc[j] + kt * 64, base + 16384 + j * 1024);
+      glds16(asrc[j] + oa, base + j * 1024);
+      glds16(wsrc[j] + ow, base + 16384 + j * 1024);
     }
   };
 
@@ -133,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = tn * 128 + wc * 64 + j * 32 + r;
-          epi_store<EPI, T>(p, row, col, acc[i][j][e]);
+          epi_store<EPI, T, NP != 0>(p, row, col, acc[i][j][e]);
         }
       }
     }
@@ -225,14 +247,14 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmParams p) {
     }
 }
 
-template <typename T>
+template <typename T, int NP = 0>
 static void launch16(int epi, const GemmParams& p, dim3 g, hipStream_t s) {
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS>), g, dim3(256), 0, s, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_GELU>), g, dim3(256), 0, s, p); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_RESID>), g, dim3(256), 0, s, p); break;
-    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_ACT_F32>), g, dim3(256), 0, s, p); break;
-    case EPI_PATCH: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_GELU, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_RESID, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_ACT_F32, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH, NP>), g, dim3(256), 0, s, p); break;
   }
 }
 
@@ -241,6 +263,12 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
   if (p.N % 128) return "gemm: N must be a multiple of 128";
   if (p.K % (dtype == AACLIP_F32 ? 16 : 64)) return "gemm: K must be a multiple of 64 (16 for f32)";
   if (p.lda % 8 || p.ldc % 2) return "gemm: lda must be a multiple of 8, ldc of 2";
+  if (dtype == AACLIP_F16X2) {
+    if (p.lda < 2L * p.K) return "gemm: split fp16 rows of A are [hi K | lo K]: lda must be >= 2K";
+    if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU) && p.ldc < 2L * p.N)
+      return "gemm: split fp16 output rows are [hi N | lo N]: ldc must be >= 2N";
+    if ((long)p.K * 3 / 64 >= 98304) return "gemm: K too large for the split kernels";
+  }
   if (epi < 0 || epi > EPI_PATCH) return "gemm: unknown epilogue";
   if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID) && !p.bias) return "gemm: bias required";
   if (epi == EPI_PATCH && (!p.pos || p.P <= 0 || p.L <= p.P)) return "gemm: patch epilogue needs pos, P, L";
@@ -256,7 +284,15 @@ static thread_local const char* g_launch_err = nullptr;
 void set_launch_error(const char* msg) { if (!g_launch_err) g_launch_err = msg; }
 const char* take_launch_error() { const char* m = g_launch_err; g_launch_err = nullptr; return m; }
 
+// split fp16: the 256-tile kernel walks an even number of (virtual) K tiles
+static bool split256_applicable(const GemmParams& p) {
+  const int nk = (p.K >> 6) * (p.w_exact16 ? 2 : 3);
+  return p.N % 256 == 0 && p.K % 64 == 0 && p.ldc % 8 == 0 && (p.scale_cols % 4) == 0 && (nk & 1) == 0 &&
+         (long)256 * p.lda < (1L << 29) && (long)256 * p.K < (1L << 28);
+}
+
 bool gemm256_applicable(int dtype, const GemmParams& p) {
+  if (dtype == AACLIP_F16X2) return split256_applicable(p);
   return dtype != AACLIP_F32 && p.N % 256 == 0 && p.K % 64 == 0 && p.ldc % 8 == 0 && (p.scale_cols % 4) == 0 &&
          (long)256 * p.lda < (1L << 30) && (long)256 * p.K < (1L << 30);
 }
@@ -299,13 +335,23 @@ static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t
 // True when launch_gemm will run one of the 16x16x32 256-tile kernels (gemm256t.hip) on the whole problem:
 // those are the kernels whose epilogue implements the LayerNorm-folding options of GemmParams.
 bool gemm_routes_to_256t(int dtype, const GemmParams& p) {
-  if (dtype == AACLIP_F32 || !gemm256_applicable(dtype, p) || p.M < 4096) return false;
+  if (dtype == AACLIP_F32 || dtype == AACLIP_F16X2 || !gemm256_applicable(dtype, p) || p.M < 4096) return false;
   if (!(g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60))) return false;   // > 1: measurement library
   if (g_tail_peel) return false;
   return true;
 }
 
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
+  if (dtype == AACLIP_F16X2) {   // split fp16: the default 256-tile kernel from M = 4096 rows, else the 128-tile kernel
+    if (g_gemm_variant != 1 && split256_applicable(p) && p.M >= 4096) {
+      launch_gemm256t(dtype, epi, p, s, 14);
+      return;
+    }
+    dim3 g(((p.M + 127) / 128) * (p.N / 128));
+    if (p.w_exact16) launch16<f16, 2>(epi, p, g, s);
+    else launch16<f16, 3>(epi, p, g, s);
+    return;
+  }
   // variants: 0 automatic (256-tile kernels from M = 4096 rows), 1 the 128-tile kernel, >= 2 (measurement library) 256-tile
   // kernels at any M
   if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {

@@ -36,7 +36,7 @@ AACLIP_DEV float row16_sum(float x) {
   return x;
 }
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
-template <typename T, int EPI>
+template <typename T, int EPI, bool SPLIT = false>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane,
                              const f32x2* ab_pre = nullptr) {
   typedef typename Elem<T>::vec4 vec4;
@@ -87,32 +87,60 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[mi][ni][j] = fmaf(ab[mi][0], acc[mi][ni][j], ab[mi][1] * sv[ni][j]);
           }
-          vec4 o;
+          vec4 o, o2;
+          float vv[4];
           if (EPI == EPI_BIAS_GELU) {
             f32x2 g0 = {acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]};
             f32x2 g1 = {acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]};
             g0 = gelu_fast2(g0);
             g1 = gelu_fast2(g1);
-            o[0] = from_float<T>(g0[0]); o[1] = from_float<T>(g0[1]);
-            o[2] = from_float<T>(g1[0]); o[3] = from_float<T>(g1[1]);
+            vv[0] = g0[0]; vv[1] = g0[1]; vv[2] = g1[0]; vv[3] = g1[1];
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float v = acc[mi][ni][j] + bv[ni][j];
               if (n_base + nl + j < p.scale_cols) v *= p.scale;
-              o[j] = from_float<T>(v);
+              vv[j] = v;
             }
           }
           const int m = mi * 16 + c16;
-          *(vec4*)(st + m * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
+          if constexpr (SPLIT) {
+            // split fp16 rows: the hi and lo tiles of a pass are staged side by side (passes 2, 3 reuse the LDS of
+            // passes 0, 1: a wave's LDS accesses execute in order) and stored as two row segments N columns apart
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f16 hi, lo;
+              split16(vv[j], hi, lo);
+              o[j] = hi;
+              o2[j] = lo;
+            }
+            char* sp = st + (m & 63) * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2;
+            *(vec4*)sp = o;
+            *(vec4*)(sp + 8192) = o2;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = from_float<T>(vv[j]);
+            *(vec4*)(st + m * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
+          }
         }
       }
 #pragma unroll
       for (int it = 4 * pass; it < 4 * pass + 4; ++it) {
         const int m = it * 8 + (lane >> 3), c = lane & 7;
-        const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
         const int row = m_base + m;
-        if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
+        if constexpr (SPLIT) {
+          const char* sp = st + (m & 63) * 128 + ((c ^ (m & 7)) << 4);
+          const u32x4 vh = *(const u32x4*)sp;
+          const u32x4 vl = *(const u32x4*)(sp + 8192);
+          if (row < p.M) {
+            T* orow = (T*)p.out + (long)row * p.ldc + n_base + c * 8;
+            ST_OUT((u32x4*)orow, vh);
+            ST_OUT((u32x4*)(orow + p.N), vl);
+          }
+        } else {
+          const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
+          if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
+        }
       }
     }
   } else {
@@ -936,7 +964,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_256w_kernel(GemmParams p, int P
 //   issue    A0(t+1)@L(t,P0)  B1(t+1)@L(t,P1)  A1(t+1)@L(t,P2)  B0(t+2)@L(t,P3)
 //   confirm  B1(t)@L(t,P0)    A1(t)@L(t,P1)    B0(t+1)@L(t,P2)  A0(t+1)@L(t,P3)
 //   read     A0(t)@L(t,P0)    B1(t)@L(t,P1)    A1(t)@L(t,P2)    B0(t+1)@L(t,P3)
-template <typename T, int EPI>
+// NP = 0: plain 16-bit operands; NP = 3 / 2: split fp16 operands (common.h), 3 / 2 virtual K tiles per K tile
+template <typename T, int EPI, int NP = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[131072];
@@ -967,6 +996,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     const long long t0 = __builtin_amdgcn_s_memtime();
     while ((long long)__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(64);
   }
+  const int ldw = NP == 3 ? 2 * p.K : p.K;   // W row stride (elements)
+  const int K2 = 2 * p.K;                    // bytes from a split row's hi plane to its lo plane
   int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];   // byte offsets
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub)
@@ -982,14 +1013,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
       srcA[sub][j] = ((ar - tm * 256) * (int)p.lda + chunk * 8) * 2;
       dstA[sub][j] = ga * 1024;
       tile_src_id(gw * 64 + lane, row, chunk);
-      srcW[sub][j] = (row * p.K + chunk * 8) * 2;
+      srcW[sub][j] = (row * ldw + chunk * 8) * 2;
       dstW[sub][j] = 32768 + gw * 1024;
     }
   // the descriptors must be PROVABLY wave-uniform, or hipcc wraps every buffer_load ... lds of the K loop in a
   // waterfall loop (v_readfirstlane x4, compare, s_and_saveexec): it lost the proof when the folding epilogue was
   // added and the residual GEMMs ran 15 % slower with an unchanged K loop in source
   const T* baseA = uniform_ptr((const T*)p.A + (long)tm * 256 * p.lda);
-  const T* baseW = uniform_ptr((const T*)p.W + (long)tn * 256 * p.K);
+  const T* baseW = uniform_ptr((const T*)p.W + (long)tn * 256 * ldw);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7FFFFFF0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
   int offM[2][2], offN[2][2];   // [ks][tile parity]
@@ -1020,11 +1051,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     }
   }
 
-  const int nk = p.K >> 6;
-#define DMA(rs, src, dst, st, kt) \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (st) * 65536 + dst), 16, src, (kt) * 128, 0, 0);
-#define GA(sub, st, kt) { DMA(rsA, srcA[sub][0], dstA[sub][0], st, kt) DMA(rsA, srcA[sub][1], dstA[sub][1], st, kt) }
-#define GW(sub, st, kt) { DMA(rsW, srcW[sub][0], dstW[sub][0], st, kt) DMA(rsW, srcW[sub][1], dstW[sub][1], st, kt) }
+  const int nk = (p.K >> 6) * (NP ? NP : 1);   // (virtual) K tiles
+#define DMA(rs, src, dst, st, so) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (st) * 65536 + dst), 16, src, so, 0, 0);
+#define GA(sub, st, kt) { const int so = split_off_a<NP>(kt, K2); DMA(rsA, srcA[sub][0], dstA[sub][0], st, so) DMA(rsA, srcA[sub][1], dstA[sub][1], st, so) }
+#define GW(sub, st, kt) { const int so = split_off_w<NP>(kt, K2); DMA(rsW, srcW[sub][0], dstW[sub][0], st, so) DMA(rsW, srcW[sub][1], dstW[sub][1], st, so) }
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define BAR __builtin_amdgcn_s_barrier();
@@ -1109,7 +1140,26 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef MM
 #undef QUADX
 #undef KTILE
-  epilogue256t<T, EPI>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
+  epilogue256t<T, EPI, NP != 0>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
+}
+
+// split fp16 (AACLIP_F16X2): the default kernel on 3 (W split) or 2 (W exact in fp16) virtual K tiles per K tile
+template <int NP>
+static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
+  const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
+  const int PN = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0) ? 3 : (tiles_n % 2 == 0) ? 2 : 1;
+  const int patches_n = tiles_n / PN, PMx = 8;
+  const int pm_x = (tiles_m + PMx - 1) / PMx;
+  const int total_x = patches_n * pm_x;
+  dim3 gx(((total_x + 7) / 8) * 8 * PMx * PN), b(512);
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_RESID, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_ACT_F32, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_PATCH, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    default: set_launch_error("gemm: no 256-tile kernel for this epilogue");
+  }
 }
 
 template <typename T>
@@ -1238,7 +1288,10 @@ void read_gemm_stamps(double* out6, int nwaves) {
 #endif  // AACLIP_MEASURE
 
 void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped) {
-  if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped);
+  if (dtype == AACLIP_F16X2) {
+    if (p.w_exact16) launch_split<2>(epi, p, s);
+    else launch_split<3>(epi, p, s);
+  } else if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped);
   else launch_t<bf16>(epi, p, s, overlapped);
 }
 

@@ -28,6 +28,10 @@ struct GemmParams {
   float* stats_out;        // EPI_BIAS_RESID: per row and 64-column slice (sum, sum of squares) of the new rows, [M][N/64][2]
   const float* row_ab;     // EPI_BIAS / EPI_BIAS_GELU: per row (a, b); value = a*acc + b*col_s[n] + bias[n]
   const float* col_s;      //   [N] row sums of the (gamma-scaled) weight
+  // AACLIP_F16X2 (split fp16, common.h): A is [M, >= 2K] (hi | lo per row, lda = row stride), W is [N, 2K] (hi | lo)
+  // or, with w_exact16, [N, K] (the weight is exact in fp16: the Ah.Wl product is skipped); 16-bit outputs are split
+  // rows too ([M, >= 2N], ldc = row stride, lo plane N columns after the hi plane).
+  int w_exact16;
 };
 
 const char* gemm_check(int dtype, int epi, const GemmParams& p);
@@ -89,6 +93,7 @@ void launch_blur_upsample(const float* pre, float* out, int B, int g, int S, int
                           hipStream_t s);
 void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int S, hipStream_t s);
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
+void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s);   // fp32 [rows, D] -> split fp16 [rows, 2D]
 // LayerNorm folding: [M][slots][2] partial (sum, sumsq) -> [M][2] (rstd, -mean*rstd)
 void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s);
 bool gemm_routes_to_256t(int dtype, const GemmParams& p);   // launch_gemm will run a kernel with the folding epilogue

@@ -35,7 +35,21 @@ AACLIP_DEV void store4<bf16>(bf16* p, f32x4 v) {
 
 // LayerNorm over the last dim, reference model/transformer.py:37-43 (eps 1e-5),
 // two-pass statistics in registers; out may alias x when T == float.
-template <typename T, int NCH>
+// split fp16 row (AACLIP_F16X2): 4 values -> hi plane at p, lo plane `width` halves further
+AACLIP_DEV void store4_split(f16* p, f32x4 v, int width) {
+  f16x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f16 a, c;
+    split16(v[e], a, c);
+    hi[e] = a;
+    lo[e] = c;
+  }
+  *(f16x4*)p = hi;
+  *(f16x4*)(p + width) = lo;
+}
+
+template <typename T, int NCH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* out, long rows, float eps) {
   constexpr int D = NCH * 256;
@@ -63,7 +77,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     f32x4 g = *(const f32x4*)(w + col), bb = *(const f32x4*)(b + col), y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
-    store4<T>(out + row * D + col, y);
+    if constexpr (SPLIT) store4_split(out + row * 2 * D + col, y, D);
+    else store4<T>(out + row * D + col, y);
   }
 }
 
@@ -79,9 +94,21 @@ static void ln_dispatch(const float* x, const float* w, const float* b, T* out, 
   }
 }
 
+static void ln_dispatch_split(const float* x, const float* w, const float* b, f16* out, long rows, int D, float eps,
+                              hipStream_t s) {
+  dim3 g((unsigned)((rows + 3) / 4));
+  switch (D / 256) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<f16, 1, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<f16, 2, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<f16, 3, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 4: hipLaunchKernelGGL((layernorm_kernel<f16, 4, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+  }
+}
+
 void launch_layernorm(int out_dtype, const float* x, const float* w, const float* b, void* out, long rows, int D,
                       float eps, hipStream_t s) {
-  if (out_dtype == AACLIP_F32) ln_dispatch<float>(x, w, b, (float*)out, rows, D, eps, s);
+  if (out_dtype == AACLIP_F16X2) ln_dispatch_split(x, w, b, (f16*)out, rows, D, eps, s);
+  else if (out_dtype == AACLIP_F32) ln_dispatch<float>(x, w, b, (float*)out, rows, D, eps, s);
   else if (out_dtype == AACLIP_F16) ln_dispatch<f16>(x, w, b, (f16*)out, rows, D, eps, s);
   else ln_dispatch<bf16>(x, w, b, (bf16*)out, rows, D, eps, s);
 }
@@ -163,7 +190,7 @@ void launch_adapter_mix_fold(int dtype, float* x, const float* a, long rows, int
 // Unfold non-overlapping ps x ps patches of an NCHW fp32 image into GEMM rows:
 // cols[(b*g*g + py*g + px)][c*ps*ps + ky*ps + kx], zero padded to Kpad
 // (conv1 of reference model/transformer.py:359-365 as a GEMM).
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int C,
                                                      int H, int W, int ps, int Kpad) {
   const int g = H / ps, gw = W / ps;
@@ -176,14 +203,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
       int c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
       v = img[(((long)b * C + c) * H + py * ps + ky) * W + px * ps + kx];
     }
-    cols[row * Kpad + k] = from_float<T>(v);
+    if constexpr (SPLIT) {
+      f16 hi, lo;
+      split16(v, hi, lo);
+      cols[row * 2 * Kpad + k] = hi;
+      cols[row * 2 * Kpad + Kpad + k] = lo;
+    } else {
+      cols[row * Kpad + k] = from_float<T>(v);
+    }
   }
 }
 
 void launch_im2col(int dtype, const float* img, void* cols, int B, int C, int H, int W, int ps, int Kpad,
                    hipStream_t s) {
   dim3 g((unsigned)((long)B * (H / ps) * (W / ps)));
-  if (dtype == AACLIP_F32)
+  if (dtype == AACLIP_F16X2)
+    hipLaunchKernelGGL((im2col_kernel<f16, true>), g, dim3(256), 0, s, img, (f16*)cols, B, C, H, W, ps, Kpad);
+  else if (dtype == AACLIP_F32)
     hipLaunchKernelGGL(im2col_kernel<float>, g, dim3(256), 0, s, img, (float*)cols, B, C, H, W, ps, Kpad);
   else if (dtype == AACLIP_F16)
     hipLaunchKernelGGL(im2col_kernel<f16>, g, dim3(256), 0, s, img, (f16*)cols, B, C, H, W, ps, Kpad);
@@ -241,7 +277,10 @@ __global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ ds
 }
 void launch_gather_rows(int dtype, const void* src, void* dst, const int32_t* tokens, int n, int T, int D, int mode,
                         hipStream_t s) {
-  if (dtype == AACLIP_F32)
+  if (dtype == AACLIP_F16X2)   // a split row is 2D halves = D words
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(n), dim3(256), 0, s, (const float*)src, (float*)dst, tokens, T,
+                       D, mode);
+  else if (dtype == AACLIP_F32)
     hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(n), dim3(256), 0, s, (const float*)src, (float*)dst, tokens, T,
                        D, mode);
   else
@@ -362,6 +401,21 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
     store4<T>(dst + i * 4, *(const f32x4*)(src + i * 4));
 }
+// fp32 rows [rows, D] -> split fp16 rows [rows, 2D]
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, f16* __restrict__ dst, long n4,
+                                                         int d4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / d4;
+    const int c = (int)(i - r * d4) * 4;
+    store4_split(dst + r * 8 * d4 + c, *(const f32x4*)(src + i * 4), 4 * d4);
+  }
+}
+void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s) {
+  const long n4 = rows * D / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, (f16*)dst, n4, D / 4);
+}
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s) {
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
@@ -402,6 +456,31 @@ __global__ __launch_bounds__(256) void vv_spread_kernel(const T* __restrict__ v,
     }
   }
 }
+// split fp16: v rows [B*L][hi D | lo D] -> qkv rows l*B + b of [q k v hi | q k v lo]; q = v * scale, split again
+__global__ __launch_bounds__(256) void vv_spread_split_kernel(const f16* __restrict__ v, f16* __restrict__ qkv, int B,
+                                                              int L, int D, float scale) {
+  const long n4 = (long)B * L * D / 4;
+  const int d4 = D / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const int b = (int)(r / L), l = (int)(r % L);
+    const f16* src = v + r * 2 * D + c;
+    f16* dst = qkv + ((long)l * B + b) * 6 * D + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16 hi = src[j], lo = src[D + j];
+      f16 qh, ql;
+      split16(((float)hi + (float)lo) * scale, qh, ql);
+      dst[j] = qh;
+      dst[3 * D + j] = ql;
+      dst[D + j] = hi;
+      dst[4 * D + j] = lo;
+      dst[2 * D + j] = hi;
+      dst[5 * D + j] = lo;
+    }
+  }
+}
 // ctx rows l*B + b -> rows b*L + l
 template <typename T>
 __global__ __launch_bounds__(256) void vv_regroup_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int L,
@@ -424,7 +503,9 @@ static unsigned vv_blocks(long n4) {
 }
 void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s) {
   const unsigned g = vv_blocks((long)B * L * D / 4);
-  if (dtype == AACLIP_F16)
+  if (dtype == AACLIP_F16X2)
+    hipLaunchKernelGGL(vv_spread_split_kernel, dim3(g), dim3(256), 0, s, (const f16*)v, (f16*)qkv, B, L, D, scale);
+  else if (dtype == AACLIP_F16)
     hipLaunchKernelGGL(vv_spread_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)v, (f16*)qkv, B, L, D, scale);
   else if (dtype == AACLIP_BF16)
     hipLaunchKernelGGL(vv_spread_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)v, (bf16*)qkv, B, L, D, scale);
@@ -432,6 +513,11 @@ void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, 
     hipLaunchKernelGGL(vv_spread_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)v, (float*)qkv, B, L, D, scale);
 }
 void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s) {
+  if (dtype == AACLIP_F16X2) {   // split rows: 2D halves each
+    hipLaunchKernelGGL(vv_regroup_kernel<f16>, dim3(vv_blocks((long)B * L * D / 2)), dim3(256), 0, s, (const f16*)src,
+                       (f16*)dst, B, L, 2 * D);
+    return;
+  }
   const unsigned g = vv_blocks((long)B * L * D / 4);
   if (dtype == AACLIP_F16)
     hipLaunchKernelGGL(vv_regroup_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)src, (f16*)dst, B, L, D);

@@ -98,7 +98,8 @@ class AdaptedCLIP(nn.Module):
         n_levels = len(self.levels)
         blocks = list(v.transformer.resblocks)
         iqm_on = text_embeddings is not None
-        dt = engine.torch_dtype(code)
+        icode = engine.plain_code(code)     # the IQM side branch has no split-fp16 kernels: exact fp32 under fp16x2
+        dt = engine.torch_dtype(icode)
         P = L - 1
         vis_cat = torch.empty(B, n_levels * P, self.iqm_hidden_size, dtype=dt, device=xs.device) if iqm_on else None
         # the whole tower with its adapters in ONE library call; the stream after every level stays in its own buffer
@@ -117,10 +118,10 @@ class AdaptedCLIP(nn.Module):
             if last:
                 det_token = det
             if iqm_on:
-                self._iqm_project_level(tap, k, vis_cat, B, L, code)
+                self._iqm_project_level(tap, k, vis_cat, B, L, icode)
         if not iqm_on:
             return seg_tokens, det_token, None
-        return seg_tokens, det_token, self._iqm_branch(xs, vis_cat, text_embeddings, B, L, code)
+        return seg_tokens, det_token, self._iqm_branch(xs, vis_cat, text_embeddings, B, L, icode)
 
     # -- reference model/adapter.py:205-208: query_adapters[k](ln_post(tap k)) for the patch rows, written into the
     #    slice of the concatenated visual features (torch.cat over dim 1, :210-211) that level k owns

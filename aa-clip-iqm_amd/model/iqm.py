@@ -133,6 +133,7 @@ class IQM(nn.Module):
         engine.require_gpu(query_embeds, "IQM")
         if code is None:
             code = engine.dtype_code(getattr(self, "precision", "fp32"))
+        code = engine.plain_code(code)          # no split-fp16 kernels on this side branch: exact fp32 under fp16x2
         dt = engine.torch_dtype(code)
         B, nq, D = query_embeds.shape
         if encoder_hidden_states is None or text_encoder_hidden_states is None:

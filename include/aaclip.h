@@ -14,6 +14,16 @@
  *  - `dtype` selects the arithmetic type of the matrix products:
  *      AACLIP_F32  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), parity path
  *      AACLIP_F16 / AACLIP_BF16  16-bit operands, fp32 accumulate (v_mfma_f32_32x32x16)
+ *      AACLIP_F16X2  split fp16: every matrix-product operand is carried as hi = fp16(v) plus lo = fp16(v - hi)
+ *                    (~21 significant bits) and every product A.W^T is accumulated as Ah.Wh^T + Al.Wh^T + Ah.Wl^T
+ *                    on the fp16 MFMAs into one fp32 accumulator (attention: 3 products for q.k^T, 2 for p.v with p
+ *                    rounded to fp16 once).  The mode that meets 1e-3 abs + 1e-2 rel against the fp32 reference on
+ *                    taps and anomaly maps at MFMA speed.  A split row of logical width C is stored as C hi halves
+ *                    followed by C lo halves (4 bytes per element, row stride >= 2C halves); this holds for weights
+ *                    ([out, 2*in]), for the 16-bit inputs / outputs of aaclip_gemm and for the packed q|k|v and
+ *                    context rows of aaclip_attention.  A weight whose values are exact in fp16 (OpenAI's CLIP
+ *                    checkpoints are stored in fp16) may be passed as plain fp16 [out, in] where an `exact16` flag
+ *                    exists (aaclip_block_weights): the Ah.Wl^T product is then skipped.
  *    Weights of matrix products are passed already converted to `dtype`, row-major
  *    [out_features, in_features] exactly like nn.Linear.weight.  LayerNorm
  *    parameters, biases, embeddings, the residual stream and all outputs are fp32.
@@ -30,9 +40,9 @@
 extern "C" {
 #endif
 
-#define AACLIP_ABI_VERSION 3
+#define AACLIP_ABI_VERSION 4
 
-enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2 };
+enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2, AACLIP_F16X2 = 3 };
 enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1, AACLIP_ACT_RELU = 2 };
 /* generic GEMM epilogues (aaclip_gemm) */
 enum { AACLIP_EPI_BIAS = 0, AACLIP_EPI_BIAS_GELU = 1, AACLIP_EPI_BIAS_RESID = 2, AACLIP_EPI_ACT_F32 = 3 };
@@ -53,7 +63,7 @@ typedef struct aaclip_block_weights {
   /* ABI version >= 3: sizeof(aaclip_block_weights) as the CALLER compiled it.  Every entry point that takes this
    * struct rejects (rc < 0, nothing launched) an element whose struct_bytes differs from the library's own sizeof, so
    * a binding generated from an older header (13 or 19 pointer fields, no size field: its first word is the ln1_w
-   * pointer) is refused instead of being read past its end. */
+   * pointer; or version 3's 20 fields without `exact16`) is refused instead of being read past its end. */
   size_t struct_bytes;
   const float* ln1_w;   /* [D] */
   const float* ln1_b;
@@ -81,7 +91,12 @@ typedef struct aaclip_block_weights {
   const void* qkv_w_fold;  /* [3D, D] dtype: in_proj_weight * ln_1.weight[None, :] */
   const float* qkv_fold_s; /* [3D] */
   const float* qkv_fold_b; /* [3D]: in_proj_bias + in_proj_weight @ ln_1.bias */
+  /* ABI version >= 4, AACLIP_F16X2 only (ignored otherwise): bit mask of the matrix weights above that are passed as
+   * PLAIN fp16 [out, in] because every value is exact in fp16 (lo half all zero); the others are split [out, 2*in]. */
+  unsigned exact16;
 } aaclip_block_weights;
+enum { AACLIP_EXACT16_QKV = 1, AACLIP_EXACT16_OUT = 2, AACLIP_EXACT16_FC = 4, AACLIP_EXACT16_PROJ = 8,
+       AACLIP_EXACT16_ADAPTER = 16 };
 
 /* Patch embedding + class token + positional embedding + ln_pre.
  * Replaces reference model/adapter.py:139-156 (== model/transformer.py:507-526).

@@ -29,15 +29,19 @@ import pytest
 import torch
 
 from aaclip_hip import engine, synth
-from aaclip_hip._lib import BF16, F16, F32
+from aaclip_hip._lib import BF16, F16, F16X2, F32
 from conftest import GOLDEN, REPO
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
-NAME = {F32: "fp32", F16: "fp16", BF16: "bf16"}
-FEATURE_TOL = {F32: (1e-4, 1e-3), F16: (1e-3, 1e-2)}          # north star for fp16; 10x tighter for fp32
-MAP_TOL = {F32: ((1e-4, 1e-3), (1e-4, 1e-3)), F16: ((4e-3, 1e-2), (6e-3, 1e-2))}   # (per level, level sum)
-TAP_TOL = {F32: (1e-4, 1e-3), F16: (4e-3, 1e-2)}              # raw residual stream, values O(1..4)
+NAME = {F32: "fp32", F16: "fp16", BF16: "bf16", F16X2: "fp16x2"}
+NORTH_STAR = (1e-3, 1e-2)                                      # BASELINE.json: 1e-3 abs + 1e-2 rel vs the fp32 reference
+# fp16x2 (split fp16 on the 16-bit MFMAs) is held to the north star on EVERY output: features, raw taps, pooled
+# embedding, per-level and summed pre-blur maps.  Plain fp16 meets it on features only (see the module docstring).
+FEATURE_TOL = {F32: (1e-4, 1e-3), F16: NORTH_STAR, F16X2: NORTH_STAR}
+MAP_TOL = {F32: ((1e-4, 1e-3), (1e-4, 1e-3)), F16: ((4e-3, 1e-2), (6e-3, 1e-2)),   # (per level, level sum)
+           F16X2: (NORTH_STAR, NORTH_STAR)}
+TAP_TOL = {F32: (1e-4, 1e-3), F16: (4e-3, 1e-2), F16X2: NORTH_STAR}   # raw residual stream, values O(1..4)
 
 ERRORS = {}
 
@@ -110,7 +114,7 @@ def images4(g4):
     return synth.synth_images(4, 518, seed=int(g4["full4.seed"]))
 
 
-@pytest.mark.parametrize("code", [F32, F16])
+@pytest.mark.parametrize("code", [F32, F16X2, F16])
 def test_full_b4_adapted_forward_vs_reference_golden(dev, g4, weights, code):
     """BASELINE config 3's forward on the large-batch kernels vs the reference's B = 4 numbers: seg tokens,
     det token, pre-blur map of every level and the level sum (anchors: the reference's own 'bottle' anchors)."""
@@ -136,7 +140,7 @@ def test_full_b4_adapted_forward_vs_reference_golden(dev, g4, weights, code):
     compare(f"{tag}.b4.map_fused_vs_level_sum", fused, total, 1e-5, 1e-6)
 
 
-@pytest.mark.parametrize("code", [F32, F16])
+@pytest.mark.parametrize("code", [F32, F16X2, F16])
 def test_full_b4_fp16_native_weights(dev, weights, code):
     """The deployment case: CLIP weights that are exactly representable in fp16 (OpenAI's checkpoint is stored in fp16
     and the reference widens it on load, model/clip.py:88), so the fp16 path's weight conversion is lossless and only
@@ -165,7 +169,7 @@ def test_full_b4_fp16_native_weights(dev, weights, code):
     compare(f"{tag}.b4h.map_pre_blur_sum", fused, T(g["full4h.map_pre_blur_sum"]), sa, sr)
 
 
-@pytest.mark.parametrize("code", [F32, F16])
+@pytest.mark.parametrize("code", [F32, F16X2, F16])
 def test_full_b4_encode_image_taps_vs_reference_golden(dev, g4, weights, code):
     """BASELINE config 2 as written -- CLIP.encode_image(image, [6, 12, 18, 24]) -- on the large-batch kernels
     (256-tile GEMMs, ln folds, aaclip_blocks_to taps without copies) vs the reference's B = 4 numbers."""

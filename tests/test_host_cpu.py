@@ -296,8 +296,9 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
                            "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     checked = 0
-    for epi in range(5):
-        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}EEEvNS_10GemmParamsEiiiii:"
+    # NP = 0: plain fp16 operands; NP = 3 / 2: the split-fp16 instantiations (virtual K tiles, run-time tile offsets)
+    for epi, np_ in [(e, n) for n in (0, 3, 2) for e in range(5)]:
+        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}ELi{np_}EEEvNS_10GemmParamsEiiiii:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
         body = lines[start:end]
@@ -306,10 +307,10 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
         loop = [l.split()[0] for l in body[bars[0]:bars[-1]] if l.strip() and not l.strip().startswith((".", ";"))]
         assert loop.count("buffer_load_dwordx4") >= 16, (epi, "K loop not found")
         assert "v_readfirstlane_b32" not in loop and "s_and_saveexec_b64" not in loop, \
-            f"EPI {epi}: waterfall loop around the K-loop DMA (descriptor not provably uniform)"
-        assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi}: spill in the K loop"
+            f"EPI {epi} NP {np_}: waterfall loop around the K-loop DMA (descriptor not provably uniform)"
+        assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi} NP {np_}: spill in the K loop"
         checked += 1
-    assert checked == 5
+    assert checked == 15
 
 
 def test_tower_run_plans_one_call_with_tap_buffers(monkeypatch):
