@@ -133,3 +133,11 @@ def metrics_eval(pixel_label, image_label, pixel_preds, image_preds, class_names
         image_auc = image_ap = 0
     return {"class name": class_names, "pixel AUC": round(pixel_auc, 4) * 100, "pixel AP": round(pixel_ap, 4) * 100,
             "image AUC": round(image_auc, 4) * 100, "image AP": round(image_ap, 4) * 100}
+
+
+def visualize(*args, **kwargs):
+    """The reference's heat-map writer (forward_utils.py:316-360: cv2 colour maps + file output) is outside this
+    build (OUT OF SCOPE).  The name exists so that `from forward_utils import visualize`
+    (reference test_last.py:17-22) resolves; calling it -- `--visualize` -- says so instead of failing on cv2."""
+    raise NotImplementedError("forward_utils.visualize: visualisation is outside the MI355X hot-path build; take the "
+                              "[N, S, S] maps test_last.get_predictions returns and plot them with your own tooling")

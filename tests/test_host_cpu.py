@@ -355,3 +355,70 @@ def test_tower_run_plans_one_call_with_tap_buffers(monkeypatch):
     assert calls[0]["outs"][2] is x and calls[0]["outs"][3] is not x      # tap after block 3, block 4 in a fresh buffer
     assert calls[1]["src"] is calls[0]["outs"][3] and all(t is calls[1]["src"] for t in calls[1]["outs"])
     assert taps[0] is x and final is calls[1]["outs"][-1]
+
+
+def test_documented_import_resolution():
+    """which of the reference caller's imports (reference test_last.py:13-22) resolve to the
+    build.  With the SCRIPT directory first (plain `python /path/to/reference/test_last.py`, PYTHONPATH = build) only
+    `model` does -- the reference's model/ is a namespace portion, its dataset/ a regular package, forward_utils.py and
+    utils.py plain modules; with the BUILD first (aa-clip-iqm_amd/run_reference_script.py, or the build's own
+    test_last.py) all four do."""
+    import subprocess
+    import sys
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present on this machine")
+    build = os.path.join(REPO, "aa-clip-iqm_amd")
+    probe = (
+        "import sys, json, importlib.util as u\n"
+        "first, second = sys.argv[1], sys.argv[2]\n"
+        "sys.path[:] = [first, second] + [p for p in sys.path if p not in ('', first, second)]\n"
+        "out = {}\n"
+        "for name in ('model', 'dataset', 'forward_utils', 'utils'):\n"
+        "    s = u.find_spec(name)\n"
+        "    loc = s.origin if s.origin else list(s.submodule_search_locations)[0]\n"
+        "    out[name] = loc\n"
+        "print(json.dumps(out))\n")
+
+    def resolve(first, second):
+        r = subprocess.run([sys.executable, "-c", probe, first, second], capture_output=True, text=True, check=True,
+                           env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+        return {k: ("build" if v.startswith(build) else "reference" if v.startswith(ref) else v)
+                for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+
+    assert resolve(ref, build) == {"model": "build", "dataset": "reference", "forward_utils": "reference",
+                                   "utils": "reference"}
+    assert resolve(build, ref) == {"model": "build", "dataset": "build", "forward_utils": "build", "utils": "build"}
+    # the launcher really orders sys.path that way (no GPU needed: the probe script only prints the resolution)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for name in ("dataset", "model"):
+            os.makedirs(os.path.join(d, name))
+        open(os.path.join(d, "dataset", "__init__.py"), "w").write("WHO = 'caller'\n")
+        open(os.path.join(d, "forward_utils.py"), "w").write("WHO = 'caller'\n")
+        open(os.path.join(d, "utils.py"), "w").write("WHO = 'caller'\n")
+        script = os.path.join(d, "caller.py")
+        open(script, "w").write(
+            "import sys, importlib.util as u\n"
+            "print('RESOLVED', [u.find_spec(n).origin for n in ('dataset', 'forward_utils', 'utils')], sys.argv[1:])\n")
+        r = subprocess.run([sys.executable, os.path.join(build, "run_reference_script.py"), script, "--flag", "7"],
+                           capture_output=True, text=True, check=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESOLVED")][-1]
+        assert line.count(build) == 3 and d not in line.split("]")[0] and "['--flag', '7']" in line
+
+
+def test_reference_callers_names_exist_in_the_build():
+    """Every name reference test_last.py:13-22 imports exists in the build's modules (visualize as a stub that says it
+    is out of scope when CALLED)."""
+    import forward_utils as FU
+    import utils as U
+    from dataset import DOMAINS, get_dataset  # noqa: F401
+    from model.adapter import AdaptedCLIP  # noqa: F401
+    from model.clip import create_model  # noqa: F401
+    for n in ("get_adapted_text_embedding", "calculate_similarity_map", "metrics_eval", "visualize"):
+        assert callable(getattr(FU, n))
+    with pytest.raises(NotImplementedError):
+        FU.visualize()
+    U.setup_seed(3)
+    a = torch.nn.functional.normalize(torch.randn(5, 8), dim=-1)
+    assert torch.allclose(U.cos_sim(a[0], a), a @ a[0]) and U.cos_sim(a, a).shape == (5, 5)
