@@ -173,7 +173,7 @@ class AdaptedCLIP(nn.Module):
                        text_encoder_hidden_states=txt.view(B, te.shape[1], tp.weight.shape[0]), code=code)
         hfin = engine.residual_layernorm(out.last_hidden_state.reshape(B * 2, h), None, self.iqm_layer_norm,
                                          self.iqm_layer_norm.eps)                             # :265-266
-        return IQMOutput(hfin.view(B, 2, h))
+        return IQMOutput(hfin.view(B, 2, h), pooler_output=out.last_hidden_state.reshape(B, 2, h)[:, 0, :])
 
     # -- reference model/adapter.py:273-304
     def encode_text(self, text, adapt_text=True):

@@ -33,12 +33,11 @@ class IQMOutput:
     """What the reference returns as iqm_outputs (a transformers BaseModelOutputWithPoolingAndCrossAttentions):
     callers read .last_hidden_state [B, 2, hidden] (test_last.py:104) and .pooler_output."""
 
-    def __init__(self, last_hidden_state: torch.Tensor):
+    def __init__(self, last_hidden_state: torch.Tensor, pooler_output: Optional[torch.Tensor] = None):
         self.last_hidden_state = last_hidden_state
-
-    @property
-    def pooler_output(self) -> torch.Tensor:
-        return self.last_hidden_state[:, 0, :]
+        # reference model/iqm.py:659-660: row 0 of the ENCODER output.  AdaptedCLIP later replaces last_hidden_state by
+        # its LayerNorm (reference model/adapter.py:265) and leaves pooler_output as it was, i.e. pre-LayerNorm.
+        self.pooler_output = last_hidden_state[:, 0, :] if pooler_output is None else pooler_output
 
 
 class _SelfOutput(nn.Module):          # reference model/iqm.py:143-154 / :219-230

@@ -100,9 +100,13 @@ def evaluate(model, image_datasets: Dict[str, torch.utils.data.Dataset], text_em
             labels, preds_image = np.zeros((0,), np.int64), np.zeros((0,), np.float32)
             preds = np.zeros((0, img_size, img_size), np.float32)
         if world > 1:
+            # RCCL gathers device tensors; gloo (CPU rehearsals, AACLIP_BENCH_BACKEND=gloo) has no CUDA all_gather, so
+            # its tensors stay on the host.  Masks are 0/1: gathered as bytes (a quarter of the float32 traffic).
+            gdev = device if dist.get_backend() == "nccl" else None
             masks, labels, preds, preds_image = gather_predictions(
-                (masks.astype(np.float32), labels.astype(np.int64), preds.astype(np.float32),
-                 preds_image.astype(np.float32)), total, device=device)
+                (masks.astype(np.uint8), labels.astype(np.int64), preds.astype(np.float32),
+                 preds_image.astype(np.float32)), total, device=gdev)
+            masks = masks.astype(np.float32)
         rows.append(metrics_eval(masks, labels, preds, preds_image, class_name, domain=DOMAINS[dataset]))
         if logger:
             logger.info("%s", rows[-1])
@@ -159,12 +163,27 @@ def main(argv=None):
     parser.add_argument("--image_adapt_weight", type=float, default=0.1)
     parser.add_argument("--text_adapt_until", type=int, default=3)
     parser.add_argument("--image_adapt_until", type=int, default=6)
-    parser.add_argument("--precision", type=str, default="fp16", help="fp32 (exact), fp16 or bf16 matrix products")
+    # the reference's IQM flags (test_last.py:186-189).  Its default hidden size of 512 makes get_predictions project the
+    # two queries to 768 through an nn.Linear it creates with fresh random weights for every batch (test_last.py:110-118),
+    # i.e. a different map on every run; this build keeps the model's 768 (AdaptedCLIP's own default, adapter.py:21) and
+    # refuses anything else.  --iqm_weight is parsed and, as in the reference (fusion weights are the constants of
+    # test_last.py:66-67), not used.
+    parser.add_argument("--iqm_hidden_size", type=int, default=768)
+    parser.add_argument("--iqm_num_layers", type=int, default=2)
+    parser.add_argument("--iqm_num_heads", type=int, default=8)
+    parser.add_argument("--iqm_weight", type=float, default=0.7)
+    parser.add_argument("--precision", type=str, default="fp16",
+                        help="fp32 (exact), fp16x2 (split fp16 on the 16-bit MFMAs: inside 1e-3 + 1e-2 of fp32 on maps), "
+                             "fp16 (fastest; maps up to ~3x outside that tolerance) or bf16")
     parser.add_argument("--device_preprocess", action="store_true", help="resize + normalise on the GPU")
     parser.add_argument("--iqm", choices=["on", "off"], default="on",
                         help="on: maps = 0.6 text + 0.4 IQM like the reference; off: text-only branch")
     args = parser.parse_args(argv)
 
+    if args.iqm_hidden_size != 768:
+        parser.error("--iqm_hidden_size must be 768 (the visual features' width): for any other size the reference "
+                     "projects the queries through a randomly initialised, unsaved nn.Linear per batch "
+                     "(test_last.py:110-118), which no checkpoint can reproduce")
     setup_seed(args.seed)
     os.makedirs(args.save_path, exist_ok=True)
     logger = logging.getLogger(__name__)
@@ -186,7 +205,9 @@ def main(argv=None):
     clip_model.eval()
     model = AdaptedCLIP(clip_model=clip_model, text_adapt_weight=args.text_adapt_weight,
                         image_adapt_weight=args.image_adapt_weight, text_adapt_until=args.text_adapt_until,
-                        image_adapt_until=args.image_adapt_until, relu=args.relu).to(device)
+                        image_adapt_until=args.image_adapt_until, relu=args.relu,
+                        iqm_hidden_size=args.iqm_hidden_size, iqm_num_layers=args.iqm_num_layers,
+                        iqm_num_heads=args.iqm_num_heads).to(device)
     model.eval()
     adapt_text = load_adapters(model, args.save_path, logger)
     image_datasets = get_dataset(args.dataset, args.img_size, None, args.shot, "test", logger=logger,

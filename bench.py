@@ -306,6 +306,7 @@ def run_rank(args):
             "n_gpus": n_gpus,
             "ranks_seen": ranks_seen,
             "devices_visible": devices,
+            "threads_per_rank": torch.get_num_threads(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),

@@ -119,3 +119,35 @@ def test_bench_launcher_propagates_a_failing_rank():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--precision", "nope", "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_rccl_selftest_launches_n_ranks_on_gloo():
+    """tools/rccl_selftest.py --ranks N: the same self-launcher as bench.py; on CPU the gloo backend runs the same
+    collectives (rank-distinct all-gather contents, fp64 times, ragged gather, barriers)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rccl_selftest.py"), "--ranks", "3", "--backend",
+                        "gloo"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "world 3" in r.stdout and r.stdout.count("self-test ok") == 1
+
+
+def test_bench_rehearsal_of_the_full_workload_two_ranks():
+    """--workload full through the launcher (2 ranks, gloo rehearsal): the step ends in the all-gather of the image
+    scores like the real full path; each rank caps its intra-op threads at cores / world."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                            "OMP_NUM_THREADS")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--workload", "full", "--rehearse-cpu"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["rows_all_gathered_per_step"] == 8
+    assert "full AA-CLIP" in d["config"]["workload"] and d["value"] is None
+    assert d["threads_per_rank"] == max(1, (os.cpu_count() or 1) // 2)

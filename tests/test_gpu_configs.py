@@ -30,7 +30,7 @@ import torch
 
 from aaclip_hip import engine, synth
 from aaclip_hip._lib import BF16, F16, F16X2, F32
-from conftest import GOLDEN, REPO
+from conftest import GOLDEN, PARITY_ERRORS, REPO
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -43,7 +43,7 @@ MAP_TOL = {F32: ((1e-4, 1e-3), (1e-4, 1e-3)), F16: ((4e-3, 1e-2), (6e-3, 1e-2)),
            F16X2: (NORTH_STAR, NORTH_STAR)}
 TAP_TOL = {F32: (1e-4, 1e-3), F16: (4e-3, 1e-2), F16X2: NORTH_STAR}   # raw residual stream, values O(1..4)
 
-ERRORS = {}
+ERRORS = PARITY_ERRORS      # shared with the other GPU test files, dumped once per session (tests/conftest.py)
 
 
 def compare(name, a, b, atol, rtol):
@@ -64,15 +64,6 @@ def compare(name, a, b, atol, rtol):
     bad = err > atol + rtol * b.abs()
     assert not bad.any(), (f"{name}: {int(bad.sum())}/{bad.numel()} outside {atol}+{rtol}*|ref|; "
                            f"max err {err.max().item():.3e}")
-
-
-@pytest.fixture(scope="module", autouse=True)
-def _dump_errors():
-    yield
-    out = os.path.join(REPO, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_errors.json"), "w") as f:
-        json.dump(ERRORS, f, indent=1, sort_keys=True)
 
 
 @pytest.fixture(scope="module")

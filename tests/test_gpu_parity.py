@@ -10,6 +10,7 @@ Tolerances (written where used):
   * bf16: 8-bit mantissa; offered, not the parity path: 1e-2 abs + 5e-2 rel.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ import torch
 
 from aaclip_hip import _lib, engine, synth
 from aaclip_hip._lib import BF16, F16, F32
+from conftest import GOLDEN, PARITY_ERRORS
 from oracle import aaclip_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -515,6 +517,43 @@ def test_auroc_parity_on_synthetic_masks(dev, full_weights):
     r2 = FU.metrics_eval(masks, labels, omap.numpy(), oscore.numpy(), "synthetic", "Industrial")
     for k in ("pixel AUC", "pixel AP"):
         assert abs(r1[k] - r2[k]) <= 0.1 + 1e-9, (k, r1, r2)   # values are percentages rounded to 2 decimals
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2", "fp16"])
+def test_auroc_parity_on_map_correlated_masks(dev, full_weights, precision):
+    """AUROC where pixel ranking matters.  The random rectangles above are uncorrelated with the random-weight maps
+    (AUROC ~ 0.5, insensitive to map errors).  Here the ground truth is derived from the REFERENCE's own map of the
+    golden B = 4 run (tests/golden/full4.npz: pre-blur grids of the 4 levels -> blur, upsample, level sum as
+    reference forward_utils.py:207-213 / test_last.py:95-100,149): its top-5 % region per image, dilated by 15 pixels,
+    so the reference map scores AUROC ~ 0.9 on it and every mis-ranked pixel near the region's rim moves the
+    figure.  Asserted for every arithmetic mode: |AUROC(HIP map) - AUROC(reference map)| <= 1e-3, same for AP
+    (reference test_last.py:102-147, forward_utils.py:288-296)."""
+    import forward_utils as FU
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    g4 = np.load(os.path.join(GOLDEN, "full4.npz"))
+    anchors = T(np.load(os.path.join(GOLDEN, "full.npz"))["full.anchors_bottle"])
+    ref = 0
+    for i in range(4):
+        grid = T(g4[f"full4.map_pre_blur{i}"]).double().unsqueeze(1)
+        ref = ref + O.bilinear_align_corners(O.gaussian_blur2d(grid, 7, 1.0), 518)[:, 0]
+    thr = torch.quantile(ref.reshape(4, -1), 0.95, dim=1).view(4, 1, 1)
+    masks = torch.nn.functional.max_pool2d((ref >= thr).float().unsqueeze(1), 31, 1, 15)[:, 0].numpy().astype(np.uint8)
+    model = build_full(dev, precision, full_weights)
+    with torch.no_grad():
+        seg, det, _ = model(synth.synth_images(4, 518, seed=int(g4["full4.seed"])).to(dev))
+        amap = FU.calculate_anomaly_map(seg, anchors.to(dev), 518, domain="Industrial").cpu().double()
+    y = masks.reshape(-1)
+    a_ref, a_hip = roc_auc_score(y, ref.numpy().reshape(-1)), roc_auc_score(y, amap.numpy().reshape(-1))
+    p_ref, p_hip = average_precision_score(y, ref.numpy().reshape(-1)), average_precision_score(y, amap.numpy().reshape(-1))
+    err = (amap - ref).abs()
+    PARITY_ERRORS[f"{precision}.b4.auroc_map_correlated_masks"] = {
+        "auroc_reference_map": a_ref, "auroc_hip_map": a_hip, "abs_delta_auroc": abs(a_ref - a_hip),
+        "ap_reference_map": p_ref, "ap_hip_map": p_hip, "abs_delta_ap": abs(p_ref - p_hip),
+        "positive_fraction": float(y.mean()), "map_max_abs_err": float(err.max()),
+        "map_rms_err": float(err.pow(2).mean().sqrt())}
+    assert 0.8 < a_ref < 0.995, a_ref                     # the regime where ranking errors show
+    assert abs(a_ref - a_hip) <= 1e-3, (precision, a_ref, a_hip)
+    assert abs(p_ref - p_hip) <= 2e-3, (precision, p_ref, p_hip)
 
 
 # ----------------------------------------------------------------------------
