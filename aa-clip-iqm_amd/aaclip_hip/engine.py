@@ -54,13 +54,50 @@ def plain_code(code: int) -> int:
     return F32 if code == F16X2 else code
 
 
-def split_rows(t: torch.Tensor) -> torch.Tensor:
-    """fp32 [R, C] -> split fp16 [R, 2C]: hi = fp16(v) | lo = fp16(v - hi) (include/aaclip.h, AACLIP_F16X2).
-    Load-time / caller-side operand preparation, like the .to(dtype) of the other modes."""
+# split fp16 (include/aaclip.h AACLIP_F16X2, csrc/common.h): fixed power-of-two scales of the e4m3 correction planes
+SPLIT8_ACT_LO_EXP, SPLIT8_ACT_HI_EXP, SPLIT8_W_HI_EXP, SPLIT8_W_LO_EXP = 10, 0, 6, 17
+
+
+def _e4m3_bytes(v: torch.Tensor, exp: int) -> torch.Tensor:
+    """fp32 -> e4m3 (OCP e4m3fn) bytes of v * 2^exp, clamped to +-448; converted on the host (load-time work)."""
+    x = (v.detach().float().cpu() * float(2 ** exp)).clamp_(-448.0, 448.0)
+    return x.to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def split16_rows(t: torch.Tensor) -> torch.Tensor:
+    """fp32 [R, C] -> split16 rows [R, 2C] fp16: hi = fp16(v) | lo = fp16(v - hi) -- the attention kernel's q|k|v
+    input format (what the QKV epilogue writes)."""
     v = t.detach().float()
     hi = v.to(torch.float16)
     lo = (v - hi.float()).to(torch.float16)
     return torch.cat([hi, lo], dim=-1).contiguous()
+
+
+def split_rows(t: torch.Tensor, weight: bool = False, exact: bool = False) -> torch.Tensor:
+    """fp32 [R, C] -> split8 rows as uint8 [R, 4C]: [hi: C x fp16][lo8: C x e4m3][hi8: C x e4m3], the GEMM operand format
+    of AACLIP_F16X2 (lo8 = e4m3((v - hi) * 2^10), hi8 = e4m3(v) for activations; weights: [Wh][e4m3(W * 2^6)]
+    [e4m3((W - Wh) * 2^17)], the last plane dropped when `exact`).  Load-time / caller-side operand preparation, like
+    the .to(dtype) of the other modes; the hot path's own split rows are written by the kernels' epilogues."""
+    dev = t.device
+    v = t.detach().float().cpu()
+    hi = v.to(torch.float16)
+    lo = v - hi.float()
+    planes = [hi.contiguous().view(torch.uint8).reshape(v.shape[0], -1)]
+    if weight:
+        planes.append(_e4m3_bytes(v, SPLIT8_W_HI_EXP))
+        if not exact:
+            planes.append(_e4m3_bytes(lo, SPLIT8_W_LO_EXP))
+    else:
+        planes += [_e4m3_bytes(lo, SPLIT8_ACT_LO_EXP), _e4m3_bytes(v, SPLIT8_ACT_HI_EXP)]
+    return torch.cat(planes, dim=1).contiguous().to(dev)
+
+
+def join_split8(t: torch.Tensor, C: int) -> torch.Tensor:
+    """split8 rows (uint8 [R, 4C] or fp16 [R, 2C]) -> fp64 hi + lo8 * 2^-10 (what a product sees of an activation)."""
+    b = t.contiguous().view(torch.uint8).reshape(t.shape[0], -1).cpu()
+    hi = b[:, : 2 * C].contiguous().view(torch.float16).double()
+    lo = b[:, 2 * C: 3 * C].contiguous().view(torch.float8_e4m3fn).double() / float(2 ** SPLIT8_ACT_LO_EXP)
+    return hi + lo
 
 
 def _stream(dev: torch.device) -> int:
@@ -118,9 +155,9 @@ class WeightCache:
         self._c: Dict[Tuple[int, int, str], tuple] = {}
 
     def get(self, p: torch.Tensor, code: int, kind: str = "plain") -> torch.Tensor:
-        """kind: 'plain' | 'transpose' | 'conv'; with a '+exact' suffix and code F16X2 the result is the plain fp16
-        weight [out, in] when every value is exact in fp16 (lo half all zero), else the split [out, 2*in] one --
-        tell them apart by the shape."""
+        """kind: 'plain' | 'transpose' | 'conv'.  Code F16X2: split8 weight rows as uint8 [out, 4*in]; with a '+exact'
+        suffix the 3-plane form [out, 3*in] when every value is exact in fp16 and in_features is a multiple of 256
+        (the kernels then skip the weight-lo correction tile) -- tell them apart by the shape."""
         key = (id(p), code, kind)
         hit = self._c.get(key)
         if hit is not None and hit[0]() is p and hit[1] == p.data_ptr() and hit[2] == p._version:
@@ -138,9 +175,10 @@ class WeightCache:
             pad[:, : flat.shape[1]] = flat
             src = pad
         if code == F16X2:
-            out = split_rows(src)
-            if allow_exact and not bool(out[:, src.shape[1]:].any()):
-                out = out[:, : src.shape[1]].contiguous()
+            src32 = src.float()
+            exact = (allow_exact and src.shape[1] % 256 == 0
+                     and bool((src32.to(torch.float16).float() == src32).all()))
+            out = split_rows(src32, weight=True, exact=exact)
         else:
             out = src.to(_TORCH_DT[code]).contiguous()
         cache = self._c
@@ -215,7 +253,7 @@ def pack_block(block, code: int, adapter_weight: Optional[torch.Tensor]) -> Tupl
         if code != F16X2:
             return _keep(refs, CACHE.get(param, code))
         t = CACHE.get(param, code, "plain+exact")
-        if t.shape[1] == param.shape[1]:
+        if t.shape[1] == 3 * param.shape[1]:
             ex |= bit
         return _keep(refs, t)
 
@@ -407,7 +445,7 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     xc = _f32c(x)
     D = xc.shape[-1]
     rows = xc.numel() // D
-    oshape = xc.shape if out_code != F16X2 else (*xc.shape[:-1], 2 * D)   # split rows: [hi D | lo D]
+    oshape = xc.shape if out_code != F16X2 else (*xc.shape[:-1], 2 * D)   # split8 rows: 4 bytes per element
     out = torch.empty(oshape, dtype=_TORCH_DT[out_code], device=x.device)
     w, b = _f32c(weight), _f32c(bias)
     _lib.check(lib.aaclip_layernorm(xc.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), out_code, rows, D,
@@ -428,7 +466,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     a = split_rows(a) if code == F16X2 else a.to(_TORCH_DT[code]).contiguous()
     out = torch.empty(a.shape[0], N, dtype=torch.float32, device=x.device)
     b = _f32c(bias) if bias is not None else None
-    _lib.check(lib.aaclip_gemm(code, _lib.EPI_ACT_F32, a.data_ptr(), a.shape[1], w.data_ptr(), _ptr(b), out.data_ptr(), N,
+    lda = 2 * K if code == F16X2 else K            # split8 rows: 4 bytes per element = 2K halves
+    _lib.check(lib.aaclip_gemm(code, _lib.EPI_ACT_F32, a.data_ptr(), lda, w.data_ptr(), _ptr(b), out.data_ptr(), N,
                                a.shape[0], N, K, int(act), 0, 1.0, _stream(x.device)), "gemm")
     return out.reshape(*x.shape[:-1], N)
 
@@ -542,11 +581,17 @@ def gemm(code: int, epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[t
          act: int = 0) -> torch.Tensor:
     """aaclip_gemm on prepared operands: a [M, K] and w [N, K] in the compute dtype, bias fp32 [N] or None,
     out [M, N] (16-bit for EPI_BIAS / EPI_BIAS_GELU, fp32 for EPI_ACT_F32)."""
-    M, lda = a.shape
+    M = a.shape[0]
     N = w.shape[0]
-    K = lda // 2 if code == F16X2 else lda          # split rows: [hi K | lo K]
+    if code == F16X2:                                # split rows hold 4 bytes per element; lda / ldc count halves
+        lda = a.shape[1] * a.element_size() // 2
+        K = lda // 2
+        ldc = out.shape[1] * out.element_size() // 2 if out.dtype != torch.float32 else out.shape[1]
+    else:
+        lda = K = a.shape[1]
+        ldc = out.shape[1]
     _lib.check(_lib.load().aaclip_gemm(code, epi, a.data_ptr(), lda, w.data_ptr(), _ptr(bias), out.data_ptr(),
-                                       out.shape[1], M, N, K, int(act), 0, 1.0, _stream(a.device)), "gemm")
+                                       ldc, M, N, K, int(act), 0, 1.0, _stream(a.device)), "gemm")
     return out
 
 

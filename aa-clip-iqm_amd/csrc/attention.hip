@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 }
 
 // ---------------------------------------------------------------------------
-// Split-fp16 variant (AACLIP_F16X2, common.h): q, k, v arrive as hi + lo fp16 pairs (rows [hi 3D | lo 3D]), the
-// context leaves the same way (rows [hi D | lo D]).  Same structure as attn16_kernel; per 64-key tile a wave issues
+// Split-fp16 variant (AACLIP_F16X2, common.h): q, k, v arrive as hi + lo fp16 pairs (split16 rows [hi 3D | lo 3D]), the
+// context leaves as split8 rows ([hi D fp16 | lo8 D | hi8 D]: the A operand of the out_proj product).  Same structure as attn16_kernel; per 64-key tile a wave issues
 //   S^T = Kh.Qh^T + Kl.Qh^T + Kh.Ql^T   (24 MFMAs: scores carry ~21 bits of q and k)
 //   O^T += Vh^T.P^T + Vl^T.P^T           (16 MFMAs: P is rounded to fp16 once, v keeps its lo half)
 // Stage image: [Kh 8K][Vh 8K][Kl 8K][Vl 8K], two stages, two workgroups per CU.
@@ -430,16 +430,16 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(const f16* __restrict__
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
-        vec4 vh, vl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f16 a, c;
-          split16(o[db][4 * gi + j] * inv, a, c);
-          vh[j] = a;
-          vl[j] = c;
-        }
-        *(vec4*)(dst + db * 32 + 8 * gi + 4 * h) = vh;
-        *(vec4*)(dst + D + db * 32 + 8 * gi + 4 * h) = vl;
+        const float vv[4] = {o[db][4 * gi] * inv, o[db][4 * gi + 1] * inv, o[db][4 * gi + 2] * inv,
+                             o[db][4 * gi + 3] * inv};
+        vec4 vh;
+        uint32_t l8, h8;
+        split8x4(vv, vh, l8, h8);
+        const int col = db * 32 + 8 * gi + 4 * h;
+        *(vec4*)(dst + col) = vh;
+        uint8_t* p8 = (uint8_t*)(dst - head * 64 + D) + head * 64;   // e4m3 planes of this row: lo8 at 2D bytes, hi8 at 3D
+        *(uint32_t*)(p8 + col) = l8;
+        *(uint32_t*)(p8 + D + col) = h8;
       }
   }
 }

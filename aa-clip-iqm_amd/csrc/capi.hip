@@ -362,7 +362,8 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     char* vbuf = big + (size_t)rows * 3 * D * es;
     p.A = narrow; p.lda = sw * D; p.M = M; p.N = D; p.K = D;
     p.w_exact16 = ex & AACLIP_EXACT16_QKV;
-    p.W = (const char*)w->qkv_w + (size_t)2 * D * D * (p.w_exact16 ? 2 : es);
+    // rows 2D.. of the packed weight; a split8 weight row holds 4 (3: exact in fp16) bytes per element
+    p.W = (const char*)w->qkv_w + (size_t)2 * D * D * (dtype == AACLIP_F16X2 ? (p.w_exact16 ? 3 : 4) : es);
     p.bias = w->qkv_b + 2 * D; p.out = vbuf; p.ldc = sw * D;
     { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
     {

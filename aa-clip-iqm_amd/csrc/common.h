@@ -41,44 +41,75 @@ template <typename T> AACLIP_DEV T from_float(float v) { return (T)v; }
 template <typename T> AACLIP_DEV float to_float(T v) { return (float)v; }
 
 // ------------------------------------------------------------ split fp16 (AACLIP_F16X2)
-// A value v is carried as two fp16 numbers hi = fp16(v), lo = fp16(v - hi): 21-22 significant bits for the values
-// this path sees (|v| well inside fp16's normal range; lo goes subnormal below |v| ~ 2^-3 and then still resolves
-// 2^-24 absolute).  A split row of width C is stored as C hi values followed by C lo values (row stride >= 2C
-// halves), so a product over K becomes a product over "virtual" K tiles: for K tile j the kernels accumulate
-// Ah_j.Wh_j + Al_j.Wh_j + Ah_j.Wl_j into the same fp32 accumulator (the Al.Wl term, 2^-22 relative, is dropped).
+// A value v is carried as hi = fp16(v) plus a correction for v - hi, so that a product sees ~15-21 bits of each operand
+// instead of 11.  Two row formats (logical width C, 4 bytes per element, row stride >= 2C halves):
+//   split16 row  [hi: C x fp16][lo: C x fp16]                    lo = fp16(v - hi).  Attention inputs (q | k | v): the
+//                attention kernel runs q.k^T as Kh.Qh + Kl.Qh + Kh.Ql and p.v as Vh.P + Vl.P on the fp16 MFMAs.
+//   split8 row   [hi: C x fp16][lo8: C x e4m3][hi8: C x e4m3]    lo8 = e4m3((v - hi) * 2^10), hi8 = e4m3(v).  GEMM
+//                A operands.  Weights likewise: [Wh: K x fp16][Wh8 = e4m3(W * 2^6)][Wl8 = e4m3((W - Wh) * 2^17)]
+//                (the last plane is absent when the weight is exact in fp16).  A product over K is accumulated as
+//                Ah.Wh (fp16 MFMA) + Al8.Wh8 + Ah8.Wl8 (block-scaled e4m3 MFMA, 16x16x128, twice the fp16 rate): the
+//                correction terms are 2^-11 of the main term, so 4 significant bits in them leave ~2^-15 relative
+//                error per operand (measured on random data: 28x below plain fp16), at 2 instead of 3 MFMA time units.
+// The scales are fixed powers of two (e4m3 spans 2^-9 ... 448): activations |v| in 0.016 ... 448 and weights |w| in
+// 2.4e-4 ... 7 keep >= 4 significant bits in their correction operands; beyond, a correction operand saturates or goes
+// subnormal, which only degrades THAT element's correction towards plain fp16 -- never the main term.
+constexpr int SPLIT8_ACT_LO_EXP = 10, SPLIT8_ACT_HI_EXP = 0, SPLIT8_W_HI_EXP = 6, SPLIT8_W_LO_EXP = 17;
 AACLIP_DEV void split16(float v, f16& hi, f16& lo) {
   hi = (f16)v;
   lo = (f16)(v - (float)hi);
 }
-// virtual K tile t of a split product -> byte offsets (from the hi plane's start) of its A and W tiles;
-// K2 = bytes from a row's hi plane to its lo plane (2*K for a [.., 2K] split row).  NP = 3: both operands split;
-// NP = 2: W has no lo plane (its values are exact in fp16), products Ah.W + Al.W only.
-template <int NP> AACLIP_DEV int split_off_a(int t, int K2) {   // NP = 0: plain operands, tile t at t * 128 bytes
-  if (NP == 0) return t * 128;
-  if (NP == 3) {
-    const int j = (int)(((unsigned)t * 43691u) >> 17);
-    return j * 128 + (t - 3 * j == 1 ? K2 : 0);
-  }
-  return (t >> 1) * 128 + ((t & 1) ? K2 : 0);
+// four values -> four e4m3 bytes (value * 2^EXP, clamped to +-448: the conversion itself returns NaN on overflow)
+template <int EXP> AACLIP_DEV uint32_t pack_e4m3x4(float a, float b, float c, float d) {
+  constexpr float S = (float)(1 << EXP);
+  a = __builtin_amdgcn_fmed3f(a * S, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b * S, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c * S, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d * S, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
 }
-template <int NP> AACLIP_DEV int split_off_w(int t, int K2) {
-  if (NP == 0) return t * 128;
-  if (NP == 3) {
-    const int j = (int)(((unsigned)t * 43691u) >> 17);
-    return j * 128 + (t - 3 * j == 2 ? K2 : 0);
+// the three planes of four split8 values
+AACLIP_DEV void split8x4(const float (&v)[4], f16x4& hi, uint32_t& lo8, uint32_t& hi8) {
+  float r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (f16)v[j];
+    r[j] = v[j] - (float)hi[j];
   }
-  return (t >> 1) * 128;
+  lo8 = pack_e4m3x4<SPLIT8_ACT_LO_EXP>(r[0], r[1], r[2], r[3]);
+  hi8 = pack_e4m3x4<SPLIT8_ACT_HI_EXP>(v[0], v[1], v[2], v[3]);
 }
-template <int NP> AACLIP_DEV void split_tile_off(int t, int K2, int& offA, int& offW) {
-  if (NP == 3) {
-    const int j = (int)(((unsigned)t * 43691u) >> 17);   // t / 3 for t < 98304
-    const int r = t - 3 * j;
-    offA = j * 128 + (r == 1 ? K2 : 0);
-    offW = j * 128 + (r == 2 ? K2 : 0);
-  } else {
-    offA = (t >> 1) * 128 + ((t & 1) ? K2 : 0);
-    offW = (t >> 1) * 128;
-  }
+// Virtual K tiles of a split8 product.  K tiles (64 wide) are taken in pairs (2i, 2i+1):
+//   NP = 4: [fp16 tile 2i] [fp16 tile 2i+1] [e4m3 tile T1: Al8 . Wh8 over both] [e4m3 tile T2: Ah8 . Wl8 over both]
+//   NP = 3: the same without T2 (weight exact in fp16)
+// Every tile is rows of 128 bytes in LDS; an e4m3 tile's 128 bytes are 128 K values.  Byte offsets from the row start
+// (K = logical width): fp16 tile j at 128*j, T1 pair i at 2K + 128*i, T2 pair i at 3K + 128*i, the same on both sides.
+// kind: 0 fp16, 1 T1, 2 T2.  NP = 0: plain operands, tile t at 128*t.
+template <int NP> AACLIP_DEV int vtile_off(int t, int K, int& kind) {
+  if (NP == 0) { kind = 0; return t * 128; }
+  int i, r;
+  if (NP == 4) { i = t >> 2; r = t & 3; }
+  else { i = (int)(((unsigned)t * 43691u) >> 17); r = t - 3 * i; }   // t / 3 for t < 98304
+  kind = r < 2 ? 0 : r - 1;
+  return r < 2 ? (2 * i + r) * 128 : r * K + 128 * i;
+}
+template <int NP> AACLIP_DEV int vtile_count(int K) { return NP == 0 ? (K >> 6) : (NP == 4 ? (K >> 5) : 3 * (K >> 7)); }
+// e8m0 scale bytes of the block-scaled MFMA for an e4m3 tile of kind 1 / 2 (stored = value * 2^EXP, so scale 2^-EXP)
+AACLIP_DEV int vtile_scale_act(int kind) { return 127 - (kind == 1 ? SPLIT8_ACT_LO_EXP : SPLIT8_ACT_HI_EXP); }
+AACLIP_DEV int vtile_scale_w(int kind) { return 127 - (kind == 1 ? SPLIT8_W_HI_EXP : SPLIT8_W_LO_EXP); }
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// 16x16x128 e4m3 MFMA on two 16-byte fragments per side: lane group g = lane >> 4 holds K bytes [16g, 16g+16) in the
+// first fragment and [64 + 16g, 64 + 16g + 16) in the second (tools/mfma_f8_probe.hip), i.e. exactly the 16-byte chunks
+// g and 4 + g of a 128-byte tile row that the fp16 16x16x32 kernels read for their two k-steps.
+AACLIP_DEV f32x4 mma_e4m3(f16x8 a0, f16x8 a1, f16x8 b0, f16x8 b1, f32x4 c, int scale_a, int scale_b) {
+  const i32x4 x0 = __builtin_bit_cast(i32x4, a0), x1 = __builtin_bit_cast(i32x4, a1);
+  const i32x4 y0 = __builtin_bit_cast(i32x4, b0), y1 = __builtin_bit_cast(i32x4, b1);
+  const i32x8 a = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  const i32x8 b = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
 }
 
 // ------------------------------------------------------------ wave reductions

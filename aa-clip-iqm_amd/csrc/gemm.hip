@@ -17,17 +17,26 @@
 //   EPI_PATCH      x_f32[b*L+1+p] = acc + pos[1+p]        (conv1 as GEMM + positional, adapter.py:139-153)
 #include "common.h"
 #include "kernels.h"
+#include "mma16.h"
 
 namespace aaclip {
 
-template <typename TOut, bool SPLIT>
+// 16-bit outputs.  SPLIT (AACLIP_F16X2, common.h): S8 = false -> split16 row (hi plane, lo plane N columns further: the
+// attention kernel's input); S8 = true -> split8 row (hi plane, then the two e4m3 planes: the next product's A operand)
+template <typename TOut, bool SPLIT, bool S8>
 AACLIP_DEV void store16(const GemmParams& p, int row, int col, float v) {
-  if (SPLIT) {   // split fp16 row: hi plane, then the lo plane N columns further
+  if constexpr (SPLIT) {
+    f16* o = (f16*)p.out + (long)row * p.ldc;
     f16 hi, lo;
     split16(v, hi, lo);
-    f16* o = (f16*)p.out + (long)row * p.ldc + col;
-    o[0] = hi;
-    o[p.N] = lo;
+    o[col] = hi;
+    if (!S8) {
+      o[p.N + col] = lo;
+    } else {
+      uint8_t* o8 = (uint8_t*)(o + p.N);
+      o8[col] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_LO_EXP>(v - (float)hi, 0.f, 0.f, 0.f);
+      o8[p.N + col] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_HI_EXP>(v, 0.f, 0.f, 0.f);
+    }
   } else {
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);
   }
@@ -38,13 +47,13 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
   if (EPI == EPI_BIAS) {
     v += p.bias[col];
     if (col < p.scale_cols) v *= p.scale;
-    store16<TOut, SPLIT>(p, row, col, v);
+    store16<TOut, SPLIT, false>(p, row, col, v);
   } else if (EPI == EPI_BIAS_GELU) {
     // 16-bit outputs: the polynomial erf of common.h (error far below the output rounding), same in every 16-bit kernel so that
     // results do not depend on which tile size a batch selects (split fp16 included: the polynomial's 1.2e-5 is 40x
     // below one fp16 rounding); fp32 keeps erff
     v = sizeof(TOut) == 4 ? gelu_erf(v + p.bias[col]) : gelu_fast(v + p.bias[col]);
-    store16<TOut, SPLIT>(p, row, col, v);
+    store16<TOut, SPLIT, true>(p, row, col, v);
   } else if (EPI == EPI_BIAS_RESID) {
     float* x = (float*)p.out + (long)row * p.ldc + col;
     const float r = p.resid ? p.resid[(long)row * p.ldc + col] : *x;
@@ -62,9 +71,7 @@ AACLIP_DEV void epi_store(const GemmParams& p, int row, int col, float v) {
 }
 
 // ------------------------------------------------------------------ 16-bit
-// NP = 0: plain 16-bit operands.  NP = 3 / 2 (T = f16): split fp16 operands (common.h), the K loop walks 3 (2)
-// virtual tiles per K tile.
-template <typename T, int EPI, int NP = 0>
+template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[65536];  // 2 stages x (A 16K + W 16K)
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     int ar = tm * 128 + row;
     ar = ar < p.M ? ar : p.M - 1;
     asrc[j] = (const T*)p.A + (long)ar * p.lda + chunk * 8;
-    wsrc[j] = (const T*)p.W + (long)(tn * 128 + row) * (NP == 3 ? 2 * p.K : p.K) + chunk * 8;
+    wsrc[j] = (const T*)p.W + (long)(tn * 128 + row) * p.K + chunk * 8;
   }
   // --- fragment read offsets inside a tile
   int aoff[2][4], boff[2][4];
@@ -107,19 +114,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (p.K >> 6) * (NP ? NP : 1);
+  const int nk = p.K >> 6;
   auto stage = [&](int s, int kt) {
     char* base = smem + s * 32768 + wave * 4096;
-    int oa = kt * 64, ow = kt * 64;   // element offsets of this (virtual) K tile
-    if (NP) {
-      split_tile_off<NP ? NP : 3>(kt, 2 * p.K, oa, ow);
-      oa >>= 1;
-      ow >>= 1;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      glds16(asrc[j] + oa, base + j * 1024);
-      glds16(wsrc[j] + ow, base + 16384 + j * 1024);
+      glds16(asrc[j] + kt * 64, base + j * 1024);
+      glds16(wsrc[j] + kt * 64, base + 16384 + j * 1024);
     }
   };
 
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = tn * 128 + wc * 64 + j * 32 + r;
-          epi_store<EPI, T, NP != 0>(p, row, col, acc[i][j][e]);
+          epi_store<EPI, T>(p, row, col, acc[i][j][e]);
         }
       }
     }
@@ -247,14 +248,126 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmParams p) {
     }
 }
 
-template <typename T, int NP = 0>
+template <typename T>
 static void launch16(int epi, const GemmParams& p, dim3 g, hipStream_t s) {
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS, NP>), g, dim3(256), 0, s, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_GELU, NP>), g, dim3(256), 0, s, p); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_RESID, NP>), g, dim3(256), 0, s, p); break;
-    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_ACT_F32, NP>), g, dim3(256), 0, s, p); break;
-    case EPI_PATCH: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_GELU>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_kernel<T, EPI_BIAS_RESID>), g, dim3(256), 0, s, p); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_ACT_F32>), g, dim3(256), 0, s, p); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH>), g, dim3(256), 0, s, p); break;
+  }
+}
+
+// ------------------------------------------------------------------ split fp16 (AACLIP_F16X2), small M
+// The 128x128 counterpart of the 256-tile split kernel for small batches (text tower, heads, unit tests): split8
+// operands (common.h), per pair of K tiles two fp16 tiles on v_mfma_f32_16x16x32_f16 and two (one) e4m3 correction
+// tiles on the block-scaled 16x16x128 MFMA.  4 waves (2 x 2), 64 x 64 of C per wave as 4 x 4 tiles of 16 x 16; two LDS
+// stages of (A 16 KiB + W 16 KiB) filled by the 16-byte DMA, one barrier per tile.  A rows are the MFMA's A side, so a
+// lane holds output column n = lane & 15 and rows m = 4 (lane >> 4) + j of each 16 x 16 tile.
+template <int EPI, int NP>
+__global__ __launch_bounds__(256, 2) void gemm16s_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = p.N >> 7;
+  const int tiles_m = (p.M + 127) >> 7;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  const long ldw = NP == 4 ? 2L * p.K : p.K + (p.K >> 1);   // W row stride in halves (4K / 3K bytes)
+
+  const char* asrc[4];
+  const char* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int row, chunk;
+    tile_src_s((wave * 4 + j) * 64 + lane, row, chunk);
+    int ar = tm * 128 + row;
+    ar = ar < p.M ? ar : p.M - 1;
+    asrc[j] = (const char*)p.A + ((long)ar * p.lda) * 2 + chunk * 16;
+    wsrc[j] = (const char*)p.W + ((long)(tn * 128 + row) * ldw) * 2 + chunk * 16;
+  }
+  int aoff[4][2], boff[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      aoff[i][ks] = tile_off_s(wr * 64 + i * 16 + c16, 4 * ks + q4);
+      boff[i][ks] = 16384 + tile_off_s(wc * 64 + i * 16 + c16, 4 * ks + q4);
+    }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = vtile_count<NP>(p.K);
+  auto stage = [&](int s, int kt) {
+    char* base = smem + s * 32768 + wave * 4096;
+    int kind;
+    const int off = vtile_off<NP>(kt, p.K, kind);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(asrc[j] + off, base + j * 1024);
+      glds16(wsrc[j] + off, base + 16384 + j * 1024);
+    }
+  };
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sb = smem + cur * 32768;
+    int kind;
+    (void)vtile_off<NP>(kt, p.K, kind);
+    f16x8 a[4][2], b[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        a[i][ks] = *(const f16x8*)(sb + aoff[i][ks]);
+        b[i][ks] = *(const f16x8*)(sb + boff[i][ks]);
+      }
+    if (kind == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+    } else {
+      const int sa = vtile_scale_act(kind), sw = vtile_scale_w(kind);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma_e4m3(a[i][0], a[i][1], b[j][0], b[j][1], acc[i][j], sa, sw);
+    }
+    wait_vm0();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = tm * 128 + wr * 64 + i * 16 + 4 * q4 + e;
+      if (row < p.M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi_store<EPI, f16, true>(p, row, tn * 128 + wc * 64 + j * 16 + c16, acc[i][j][e]);
+      }
+    }
+}
+
+template <int NP>
+static void launch16s(int epi, const GemmParams& p, dim3 g, hipStream_t s) {
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm16s_kernel<EPI_BIAS, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16s_kernel<EPI_BIAS_GELU, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16s_kernel<EPI_BIAS_RESID, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16s_kernel<EPI_ACT_F32, NP>), g, dim3(256), 0, s, p); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16s_kernel<EPI_PATCH, NP>), g, dim3(256), 0, s, p); break;
   }
 }
 
@@ -264,10 +377,11 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
   if (p.K % (dtype == AACLIP_F32 ? 16 : 64)) return "gemm: K must be a multiple of 64 (16 for f32)";
   if (p.lda % 8 || p.ldc % 2) return "gemm: lda must be a multiple of 8, ldc of 2";
   if (dtype == AACLIP_F16X2) {
-    if (p.lda < 2L * p.K) return "gemm: split fp16 rows of A are [hi K | lo K]: lda must be >= 2K";
+    if (p.K % 128) return "gemm: split fp16 products take K tiles in pairs: K must be a multiple of 128";
+    if (p.lda < 2L * p.K) return "gemm: split8 rows of A hold 4 bytes per element: lda (in halves) must be >= 2K";
     if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU) && p.ldc < 2L * p.N)
-      return "gemm: split fp16 output rows are [hi N | lo N]: ldc must be >= 2N";
-    if ((long)p.K * 3 / 64 >= 98304) return "gemm: K too large for the split kernels";
+      return "gemm: split output rows hold 4 bytes per element: ldc (in halves) must be >= 2N";
+    if ((long)p.K >= (1L << 20)) return "gemm: K too large for the split kernels";
   }
   if (epi < 0 || epi > EPI_PATCH) return "gemm: unknown epilogue";
   if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID) && !p.bias) return "gemm: bias required";
@@ -284,10 +398,10 @@ static thread_local const char* g_launch_err = nullptr;
 void set_launch_error(const char* msg) { if (!g_launch_err) g_launch_err = msg; }
 const char* take_launch_error() { const char* m = g_launch_err; g_launch_err = nullptr; return m; }
 
-// split fp16: the 256-tile kernel walks an even number of (virtual) K tiles
+// split fp16: K tiles are taken in pairs, and the 256-tile kernel walks an even number of virtual tiles
+// (4 per pair, or 3 when the weight is exact in fp16: then K must be a multiple of 256)
 static bool split256_applicable(const GemmParams& p) {
-  const int nk = (p.K >> 6) * (p.w_exact16 ? 2 : 3);
-  return p.N % 256 == 0 && p.K % 64 == 0 && p.ldc % 8 == 0 && (p.scale_cols % 4) == 0 && (nk & 1) == 0 &&
+  return p.N % 256 == 0 && p.K % (p.w_exact16 ? 256 : 128) == 0 && p.ldc % 8 == 0 && (p.scale_cols % 4) == 0 &&
          (long)256 * p.lda < (1L << 29) && (long)256 * p.K < (1L << 28);
 }
 
@@ -348,8 +462,8 @@ void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
       return;
     }
     dim3 g(((p.M + 127) / 128) * (p.N / 128));
-    if (p.w_exact16) launch16<f16, 2>(epi, p, g, s);
-    else launch16<f16, 3>(epi, p, g, s);
+    if (p.w_exact16) launch16s<3>(epi, p, g, s);
+    else launch16s<4>(epi, p, g, s);
     return;
   }
   // variants: 0 automatic (256-tile kernels from M = 4096 rows), 1 the 128-tile kernel, >= 2 (measurement library) 256-tile

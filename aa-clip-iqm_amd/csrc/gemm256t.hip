@@ -104,9 +104,10 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
             }
           }
           const int m = mi * 16 + c16;
-          if constexpr (SPLIT) {
-            // split fp16 rows: the hi and lo tiles of a pass are staged side by side (passes 2, 3 reuse the LDS of
-            // passes 0, 1: a wave's LDS accesses execute in order) and stored as two row segments N columns apart
+          if constexpr (SPLIT && EPI == EPI_BIAS) {
+            // split16 rows (attention inputs): the hi and lo tiles of a pass are staged side by side (passes 2, 3
+            // reuse the LDS of passes 0, 1: a wave's LDS accesses execute in order) and stored as two row segments
+            // N columns apart
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               f16 hi, lo;
@@ -117,6 +118,15 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
             char* sp = st + (m & 63) * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2;
             *(vec4*)sp = o;
             *(vec4*)(sp + 8192) = o2;
+          } else if constexpr (SPLIT) {
+            // split8 rows (the next product's A operand): hi tile as above; the e4m3 planes of a row share one
+            // 128-byte staging row, [lo8: 64 bytes][hi8: 64 bytes], 16-byte chunks swizzled like the hi tile
+            uint32_t l8, h8;
+            split8x4(vv, o, l8, h8);
+            char* sp = st + (m & 63) * 128;
+            *(vec4*)(sp + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
+            *(uint32_t*)(sp + 8192 + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
+            *(uint32_t*)(sp + 8192 + (((4 + (nl >> 4)) ^ (m & 7)) << 4) + (nl & 12)) = h8;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = from_float<T>(vv[j]);
@@ -133,9 +143,15 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           const u32x4 vh = *(const u32x4*)sp;
           const u32x4 vl = *(const u32x4*)(sp + 8192);
           if (row < p.M) {
-            T* orow = (T*)p.out + (long)row * p.ldc + n_base + c * 8;
-            ST_OUT((u32x4*)orow, vh);
-            ST_OUT((u32x4*)(orow + p.N), vl);
+            T* orow = (T*)p.out + (long)row * p.ldc;
+            ST_OUT((u32x4*)(orow + n_base + c * 8), vh);
+            if constexpr (EPI == EPI_BIAS) {
+              ST_OUT((u32x4*)(orow + p.N + n_base + c * 8), vl);
+            } else {
+              // chunk c < 4: bytes [16c, 16c+16) of this wave's 64 lo8 columns; c >= 4: of its hi8 columns
+              char* o8 = (char*)orow + 2 * p.N + (c >> 2) * p.N + n_base + (c & 3) * 16;
+              ST_OUT((u32x4*)o8, vl);
+            }
           }
         } else {
           const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
@@ -964,7 +980,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_256w_kernel(GemmParams p, int P
 //   issue    A0(t+1)@L(t,P0)  B1(t+1)@L(t,P1)  A1(t+1)@L(t,P2)  B0(t+2)@L(t,P3)
 //   confirm  B1(t)@L(t,P0)    A1(t)@L(t,P1)    B0(t+1)@L(t,P2)  A0(t+1)@L(t,P3)
 //   read     A0(t)@L(t,P0)    B1(t)@L(t,P1)    A1(t)@L(t,P2)    B0(t+1)@L(t,P3)
-// NP = 0: plain 16-bit operands; NP = 3 / 2: split fp16 operands (common.h), 3 / 2 virtual K tiles per K tile
+// NP = 0: plain 16-bit operands; NP = 4 / 3: split8 operands (common.h): per pair of K tiles two fp16 tiles and two
+// (one: weight exact in fp16) e4m3 correction tiles, all through the same phases; a phase of an e4m3 tile issues 8
+// 16x16x128 block-scaled MFMAs (32 cycles each) where an fp16 tile issues 16 16x16x32 ones (16 cycles each)
 template <typename T, int EPI, int NP = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
@@ -996,8 +1014,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     const long long t0 = __builtin_amdgcn_s_memtime();
     while ((long long)__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(64);
   }
-  const int ldw = NP == 3 ? 2 * p.K : p.K;   // W row stride (elements)
-  const int K2 = 2 * p.K;                    // bytes from a split row's hi plane to its lo plane
+  const int ldw = NP == 4 ? 2 * p.K : (NP == 3 ? p.K + (p.K >> 1) : p.K);   // W row stride in halves (4K / 3K / 2K bytes)
   int srcA[2][2], srcW[2][2], dstA[2][2], dstW[2][2];   // byte offsets
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub)
@@ -1051,11 +1068,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     }
   }
 
-  const int nk = (p.K >> 6) * (NP ? NP : 1);   // (virtual) K tiles
+  const int nk = vtile_count<NP>(p.K);   // (virtual) K tiles
 #define DMA(rs, src, dst, st, so) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (st) * 65536 + dst), 16, src, so, 0, 0);
-#define GA(sub, st, kt) { const int so = split_off_a<NP>(kt, K2); DMA(rsA, srcA[sub][0], dstA[sub][0], st, so) DMA(rsA, srcA[sub][1], dstA[sub][1], st, so) }
-#define GW(sub, st, kt) { const int so = split_off_w<NP>(kt, K2); DMA(rsW, srcW[sub][0], dstW[sub][0], st, so) DMA(rsW, srcW[sub][1], dstW[sub][1], st, so) }
+#define GA(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd); DMA(rsA, srcA[sub][0], dstA[sub][0], st, so) DMA(rsA, srcA[sub][1], dstA[sub][1], st, so) }
+#define GW(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd); DMA(rsW, srcW[sub][0], dstW[sub][0], st, so) DMA(rsW, srcW[sub][1], dstW[sub][1], st, so) }
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define BAR __builtin_amdgcn_s_barrier();
@@ -1067,15 +1084,24 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 2; ++t) \
       FN[t][ks] = *(const vec8*)((sb) + offN[ks][t] + (b) * 4096);
 #define MM(FN, a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(FN[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+// e4m3 tile: the two 16-byte fragments of a row are one 32-byte operand (common.h, mma_e4m3); W rows are the MFMA's A side
+#define MM8(FN, a, b, t, u) acc[4 * (a) + (t)][2 * (b) + (u)] = mma_e4m3(FN[u][0], FN[u][1], fm[t][0], fm[t][1], acc[4 * (a) + (t)][2 * (b) + (u)], sc_w, sc_a);
 #define QUADX(FN, a, b)                                                                      \
   {                                                                                          \
     LGKM0                                                                                    \
     PINB                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                           \
+    if (NP != 0 && kind != 0) {                                                              \
+      if constexpr (NP != 0) {                                                               \
+        MM8(FN, a, b, 0, 0) MM8(FN, a, b, 0, 1) MM8(FN, a, b, 1, 0) MM8(FN, a, b, 1, 1)      \
+        MM8(FN, a, b, 2, 0) MM8(FN, a, b, 2, 1) MM8(FN, a, b, 3, 0) MM8(FN, a, b, 3, 1)      \
+      }                                                                                      \
+    } else {                                                                                 \
     MM(FN, a, b, 0, 0, 0) MM(FN, a, b, 0, 1, 0) MM(FN, a, b, 1, 0, 0) MM(FN, a, b, 1, 1, 0)  \
     MM(FN, a, b, 2, 0, 0) MM(FN, a, b, 2, 1, 0) MM(FN, a, b, 3, 0, 0) MM(FN, a, b, 3, 1, 0)  \
     MM(FN, a, b, 0, 0, 1) MM(FN, a, b, 0, 1, 1) MM(FN, a, b, 1, 0, 1) MM(FN, a, b, 1, 1, 1)  \
     MM(FN, a, b, 2, 0, 1) MM(FN, a, b, 2, 1, 1) MM(FN, a, b, 3, 0, 1) MM(FN, a, b, 3, 1, 1)  \
+    }                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                           \
     PINB                                                                                     \
   }
@@ -1084,6 +1110,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   {                                                                                           \
     const int cur = (kt) & 1, nxt = cur ^ 1;                                                  \
     const bool more1 = (kt) + 1 < nk, more2 = (kt) + 2 < nk;                                  \
+    int kind;                                                                                 \
+    (void)vtile_off<NP>(kt, p.K, kind);                                                       \
+    const int sc_w = vtile_scale_w(kind), sc_a = vtile_scale_act(kind);                       \
+    (void)sc_w; (void)sc_a;                                                                   \
     const char* sb = smem + cur * 65536;                                                      \
     /* P0: confirm B1(kt); read A0(kt); issue A0(kt+1) */                                     \
     if (more1) WAIT_VM(4); else WAIT_VM(2);                                                   \
@@ -1138,12 +1168,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef LD_M
 #undef LD_N
 #undef MM
+#undef MM8
 #undef QUADX
 #undef KTILE
   epilogue256t<T, EPI, NP != 0>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
 }
 
-// split fp16 (AACLIP_F16X2): the default kernel on 3 (W split) or 2 (W exact in fp16) virtual K tiles per K tile
+// split fp16 (AACLIP_F16X2): the default kernel on split8 operands, 4 (3: W exact in fp16) virtual tiles per K-tile pair
 template <int NP>
 static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
   const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
@@ -1289,8 +1320,8 @@ void read_gemm_stamps(double* out6, int nwaves) {
 
 void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped) {
   if (dtype == AACLIP_F16X2) {
-    if (p.w_exact16) launch_split<2>(epi, p, s);
-    else launch_split<3>(epi, p, s);
+    if (p.w_exact16) launch_split<3>(epi, p, s);
+    else launch_split<4>(epi, p, s);
   } else if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped);
   else launch_t<bf16>(epi, p, s, overlapped);
 }

@@ -24,4 +24,8 @@ AACLIP_DEV void tile_src_id(int p, int& row, int& chunk) {
   chunk = s & 7;
 }
 
+// the same addressing for kernels outside the 256-tile family (gemm.hip: small-M split kernel)
+AACLIP_DEV int tile_off_s(int row, int chunk) { return tile_off_id(row, chunk); }
+AACLIP_DEV void tile_src_s(int p, int& row, int& chunk) { tile_src_id(p, row, chunk); }
+
 }  // namespace aaclip

@@ -35,18 +35,17 @@ AACLIP_DEV void store4<bf16>(bf16* p, f32x4 v) {
 
 // LayerNorm over the last dim, reference model/transformer.py:37-43 (eps 1e-5),
 // two-pass statistics in registers; out may alias x when T == float.
-// split fp16 row (AACLIP_F16X2): 4 values -> hi plane at p, lo plane `width` halves further
-AACLIP_DEV void store4_split(f16* p, f32x4 v, int width) {
-  f16x4 hi, lo;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    f16 a, c;
-    split16(v[e], a, c);
-    hi[e] = a;
-    lo[e] = c;
-  }
-  *(f16x4*)p = hi;
-  *(f16x4*)(p + width) = lo;
+// split8 row (AACLIP_F16X2, common.h): 4 values at column `col` of a row of logical width `width` starting at `row`:
+// hi plane (fp16), then the lo8 and hi8 planes (e4m3, one byte per element)
+AACLIP_DEV void store4_split(f16* row, int col, f32x4 v, int width) {
+  const float vv[4] = {v[0], v[1], v[2], v[3]};
+  f16x4 hi;
+  uint32_t l8, h8;
+  split8x4(vv, hi, l8, h8);
+  *(f16x4*)(row + col) = hi;
+  uint8_t* p8 = (uint8_t*)(row + width);
+  *(uint32_t*)(p8 + col) = l8;
+  *(uint32_t*)(p8 + width + col) = h8;
 }
 
 template <typename T, int NCH, bool SPLIT = false>
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     f32x4 g = *(const f32x4*)(w + col), bb = *(const f32x4*)(b + col), y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
-    if constexpr (SPLIT) store4_split(out + row * 2 * D + col, y, D);
+    if constexpr (SPLIT) store4_split(out + row * 2 * D, col, y, D);
     else store4<T>(out + row * D + col, y);
   }
 }
@@ -203,11 +202,13 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
       int c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
       v = img[(((long)b * C + c) * H + py * ps + ky) * W + px * ps + kx];
     }
-    if constexpr (SPLIT) {
-      f16 hi, lo;
-      split16(v, hi, lo);
-      cols[row * 2 * Kpad + k] = hi;
-      cols[row * 2 * Kpad + Kpad + k] = lo;
+    if constexpr (SPLIT) {   // split8 row: hi plane, lo8 plane, hi8 plane
+      f16* r = cols + row * 2 * Kpad;
+      const f16 hi = (f16)v;
+      r[k] = hi;
+      uint8_t* p8 = (uint8_t*)(r + Kpad);
+      p8[k] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_LO_EXP>(v - (float)hi, 0.f, 0.f, 0.f);
+      p8[Kpad + k] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_HI_EXP>(v, 0.f, 0.f, 0.f);
     } else {
       cols[row * Kpad + k] = from_float<T>(v);
     }
@@ -401,13 +402,13 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
     store4<T>(dst + i * 4, *(const f32x4*)(src + i * 4));
 }
-// fp32 rows [rows, D] -> split fp16 rows [rows, 2D]
+// fp32 rows [rows, D] -> split8 rows [rows, 2D halves]
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, f16* __restrict__ dst, long n4,
                                                          int d4) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const long r = i / d4;
     const int c = (int)(i - r * d4) * 4;
-    store4_split(dst + r * 8 * d4 + c, *(const f32x4*)(src + i * 4), 4 * d4);
+    store4_split(dst + r * 8 * d4, c, *(const f32x4*)(src + i * 4), 4 * d4);
   }
 }
 void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s) {

@@ -1,9 +1,11 @@
-"""GPU parity tests of the split-fp16 arithmetic (AACLIP_F16X2, precision='fp16x2'): every matrix-product operand is an
-fp16 hi + lo pair and every product runs as Ah.Wh + Al.Wh + Ah.Wl on the fp16 MFMAs (include/aaclip.h).
+"""GPU parity tests of the split-fp16 arithmetic (AACLIP_F16X2, precision='fp16x2'; include/aaclip.h, csrc/common.h):
+every matrix-product operand is fp16(v) plus a correction for v - fp16(v).  GEMMs accumulate Ah.Wh on the fp16 MFMAs and
+the two correction products Al8.Wh8 + Ah8.Wl8 on the block-scaled e4m3 MFMAs (split8 rows); attention runs q.k^T as
+three and p.v as two fp16 products on fp16 hi + lo pairs (split16 rows).
 
 The mode exists to put the 16-bit MFMA path inside BASELINE.json's tolerance (1e-3 abs + 1e-2 rel vs the fp32
-reference) on taps and anomaly maps; the kernel-level bounds here are what that needs: ~1e-5 relative on a product,
-i.e. ~100x tighter than plain fp16 (tests/test_gpu_parity.py) and within ~10x of the exact-fp32 kernels.
+reference) on taps and anomaly maps.  Kernel-level bounds here: ~1e-4 relative on a GEMM result (plain fp16: 1.5e-3;
+the correction terms carry 4 significant bits, i.e. ~2^-15 per operand), 4e-4 on an attention context.
 Full-model checks against the reference's golden vectors are in tests/test_gpu_configs.py (the `fp16x2` cases).
 """
 import pytest
@@ -37,18 +39,30 @@ def assert_close(a, b, atol, rtol, what=""):
                            f"max err {err.max().item():.3e} at ref {b.flatten()[err.argmax()].item():.3e}")
 
 
-def join(t, C):
-    """split rows [R, 2C] -> fp64 values hi + lo"""
-    return t[:, :C].double() + t[:, C:2 * C].double()
+def join16(t, C):
+    """split16 rows [R, 2C] fp16 -> fp64 values hi + lo"""
+    return t[:, :C].double().cpu() + t[:, C:2 * C].double().cpu()
 
 
-def test_split_rows_roundtrip_cpu_free(dev):
-    """engine.split_rows: hi + lo reproduces fp32 values to ~2^-22 relative (2^-24 absolute below fp16's normal range)."""
+join8 = engine.join_split8      # split8 rows -> fp64 hi + lo8 * 2^-10
+
+
+def test_split_rows_formats(dev):
+    """engine.split_rows / split16_rows: what a product sees of a value -- hi + lo -- is within 2^-21 (split16) and
+    2^-15 (split8: the correction has 4 significant bits) of the fp32 value."""
     x = synth.randn("t.split.x", (64, 256), 3.0, 1).to(dev)
-    s = engine.split_rows(x)
-    assert s.shape == (64, 512) and s.dtype == torch.float16
-    err = (join(s, 256) - x.double()).abs()
-    assert float((err / (x.double().abs() * 2.0 ** -21 + 2.0 ** -24)).max()) <= 1.0
+    s16 = engine.split16_rows(x)
+    assert s16.shape == (64, 512) and s16.dtype == torch.float16
+    err = (join16(s16, 256) - x.double().cpu()).abs()
+    assert float((err / (x.double().cpu().abs() * 2.0 ** -21 + 2.0 ** -24)).max()) <= 1.0
+    s8 = engine.split_rows(x)
+    assert s8.shape == (64, 1024) and s8.dtype == torch.uint8
+    err = (join8(s8, 256) - x.double().cpu()).abs()
+    assert float((err / (x.double().cpu().abs() * 2.0 ** -15 + 2.0 ** -19)).max()) <= 1.0
+    w = engine.split_rows(x, weight=True)
+    wx = engine.split_rows(x.half().float(), weight=True, exact=True)
+    assert w.shape == (64, 1024) and wx.shape == (64, 768)
+    assert torch.equal(w[:, :512].cpu(), s8[:, :512].cpu())            # the fp16 plane is the same
 
 
 @pytest.mark.parametrize("D", [256, 768, 1024])
@@ -56,75 +70,107 @@ def test_layernorm_split_output(dev, D):
     lib = _lib.load()
     x = synth.randn("t.ln.x", (37, D), 3.0, 1, mean=0.7)
     w, b = synth.randn("t.ln.w", (D,), 0.2, 1, 1.0), synth.randn("t.ln.b", (D,), 0.2, 1)
-    out = torch.full((37, 2 * D), float("nan"), dtype=torch.float16, device=dev)
+    out = torch.full((37, 4 * D), 0xAA, dtype=torch.uint8, device=dev)
     xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
     _lib.check(lib.aaclip_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), F16X2, 37, D, 1e-5,
                                     stream(dev)))
     ref = O.layer_norm(x.double(), w.double(), b.double())
-    assert_close(join(out, D), ref, 4e-6, 2e-6, f"layernorm split {D}")
+    assert_close(join8(out, D), ref, 6e-6, 2.0 ** -14, f"layernorm split8 {D}")
+    # the kernel's planes are exactly what the host-side split of the SAME fp32 values gives (hi, lo8, hi8 bytes)
+    hi = out[:, : 2 * D].cpu().contiguous().view(torch.float16)
+    want = engine.split_rows(hi.float() + 0.0)            # hi plane of a value that is exact in fp16
+    assert torch.equal(want[:, : 2 * D].cpu(), out[:, : 2 * D].cpu())
+    hi8 = out[:, 3 * D:].cpu().contiguous().view(torch.float8_e4m3fn).double()
+    assert float(((hi8 - ref).abs() / (ref.abs() * 2.0 ** -4 + 2.0 ** -9)).max()) <= 1.0
 
 
 def _gemm(lib, dev, epi, A, W, bias, out, K, act=0, scale_cols=0, scale=1.0):
+    """A: split8 rows (uint8 [M, 4K]); W: split8 weight rows; out: fp32 [M, N], or uint8 [M, 4N] split rows"""
     M, N = A.shape[0], W.shape[0]
-    _lib.check(lib.aaclip_gemm(F16X2, epi, A.data_ptr(), A.shape[1], W.data_ptr(), None if bias is None else bias.data_ptr(),
-                               out.data_ptr(), out.shape[1], M, N, K, act, scale_cols, scale, stream(dev)), "gemm")
+    ldc = out.shape[1] if out.dtype == torch.float32 else 2 * N
+    _lib.check(lib.aaclip_gemm(F16X2, epi, A.data_ptr(), 2 * K, W.data_ptr(), None if bias is None else bias.data_ptr(),
+                               out.data_ptr(), ldc, M, N, K, act, scale_cols, scale, stream(dev)), "gemm")
+
+
+def _planes(hi=None, p8a=None, p8b=None, rows=0, K=0):
+    """hand-built split8 rows from explicit planes: fp16 values, bytes of plane 1, bytes of plane 2 (None = zeros)"""
+    z16 = torch.zeros(rows, K, dtype=torch.float16)
+    z8 = torch.zeros(rows, K, dtype=torch.uint8)
+    parts = [(hi if hi is not None else z16).contiguous().view(torch.uint8).reshape(rows, 2 * K),
+             p8a if p8a is not None else z8, p8b if p8b is not None else z8]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def _e4m3(t):
+    return t.float().to(torch.float8_e4m3fn).view(torch.uint8)
 
 
 @pytest.mark.parametrize("M", [200, 4300])   # 128-tile kernel / 256-tile kernel
 def test_gemm_split_exact_integers(dev, M):
-    """Small integers are exact in the hi half (lo = 0): any wrong lane / fragment / virtual-tile mapping shows up
-    bit-for-bit.  A second run carries the integers in the LO halves only (hi = 0 on one operand at a time)."""
+    """Small integers are exact in fp16 and in e4m3: any wrong lane / fragment / virtual-tile / scale mapping shows up
+    bit-for-bit.  Four runs: ordinary split8 operands (corrections are zero); the integers carried ONLY by the
+    activation's lo8 plane against the weight's e4m3 hi plane (tile T1, scale 2^-(10+6)); ONLY by the activation's hi8
+    plane against the weight's lo8 plane (tile T2, scale 2^-17); and a weight passed in its 3-plane 'exact' form."""
     lib = _lib.load()
-    N, K = 256, 128
+    N, K = 256, 256
     g = torch.Generator().manual_seed(5)
     A = torch.randint(-3, 4, (M, K), generator=g).float()
     W = torch.randint(-2, 3, (N, K), generator=g).float()
     A[:, 0] += torch.arange(M).float() % 5
     W[:, 1] += torch.arange(N).float() % 3
     ref = A.double() @ W.double().t()
-    As, Ws = engine.split_rows(A.to(dev)), engine.split_rows(W.to(dev))
     out = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    As, Ws = engine.split_rows(A.to(dev)), engine.split_rows(W.to(dev), weight=True)
     _gemm(lib, dev, _lib.EPI_ACT_F32, As, Ws, None, out, K)
     assert torch.equal(out.cpu().double(), ref)
-    # A carried by its lo half: only the Al.Wh product contributes
-    Alo = torch.cat([torch.zeros_like(As[:, :K]), As[:, :K]], dim=1).contiguous()
-    _gemm(lib, dev, _lib.EPI_ACT_F32, Alo, Ws, None, out, K)
-    assert torch.equal(out.cpu().double(), ref)
-    # W carried by its lo half: only the Ah.Wl product contributes
-    Wlo = torch.cat([torch.zeros_like(Ws[:, :K]), Ws[:, :K]], dim=1).contiguous()
-    _gemm(lib, dev, _lib.EPI_ACT_F32, As, Wlo, None, out, K)
-    assert torch.equal(out.cpu().double(), ref)
+    # T1 only: value = lo8 * 2^-10 on the activation side, e4m3(W * 2^6) on the weight side
+    A1 = _planes(p8a=_e4m3(A), rows=M, K=K).to(dev)
+    W1 = _planes(p8a=_e4m3(W * 64), rows=N, K=K).to(dev)
+    _gemm(lib, dev, _lib.EPI_ACT_F32, A1, W1, None, out, K)
+    assert torch.equal(out.cpu().double() * 1024.0, ref)
+    # T2 only: e4m3(A) on the activation side, weight lo plane = W * 2^-17 stored as e4m3(W)
+    A2 = _planes(p8b=_e4m3(A), rows=M, K=K).to(dev)
+    W2 = _planes(p8b=_e4m3(W), rows=N, K=K).to(dev)
+    _gemm(lib, dev, _lib.EPI_ACT_F32, A2, W2, None, out, K)
+    assert torch.equal(out.cpu().double() * 131072.0, ref)
 
 
-@pytest.mark.parametrize("shape", [(1370, 1024, 1024), (300, 128, 64), (77, 768, 3072), (129, 384, 640),
-                                   (4100, 256, 192),     # large M, odd K/64: 9 virtual tiles -> the 128-tile kernel
+@pytest.mark.parametrize("shape", [(1370, 1024, 1024), (300, 128, 128), (77, 768, 3072), (129, 384, 640),
                                    (5000, 768, 1024),    # large M, ragged last tile: the 256-tile kernel
-                                   (4500, 1024, 4096)])  # c_proj's shape: 192 virtual tiles
+                                   (4500, 1024, 4096),   # c_proj's shape: 128 virtual tiles
+                                   (4200, 256, 640)])    # patch embed's K: 5 K-tile pairs
 def test_gemm_split_epilogues(dev, shape):
     lib = _lib.load()
     M, N, K = shape
     A = synth.randn("t.g.a", (M, K), 1.0, 2)
     W = synth.randn("t.g.w", (N, K), K ** -0.5, 2)
     bias = synth.randn("t.g.b", (N,), 0.5, 2)
-    Ad, Wd, bd = engine.split_rows(A.to(dev)), engine.split_rows(W.to(dev)), bias.to(dev)
+    Ad, Wd, bd = engine.split_rows(A.to(dev)), engine.split_rows(W.to(dev), weight=True), bias.to(dev)
     acc = A.double() @ W.double().t()
-    # operand error 2^-22 each, dropped Al.Wl 2^-22, fp32 accumulation over K, output split 2^-22: a few 1e-6 relative
-    # to the row's |a|.|w| ~ 1; asserted at 1e-5 + 1e-5 (plain fp16: 1.5e-3)
-    et = 1e-5
-    out = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device=dev)
-    _gemm(lib, dev, _lib.EPI_BIAS, Ad, Wd, bd, out, K, scale_cols=64, scale=0.125)
+    # each correction term carries 4 significant bits: ~2^-15 relative per operand, random over K -> measured ~1e-5 rms,
+    # 1.5e-4 max on rows of |a|.|w| ~ 1 (plain fp16: 6e-4 rms); asserted at 3e-4 + 1e-4 |ref|
+    ea, er = 3e-4, 1e-4
+    out = torch.full((M, 4 * N), 0xAA, dtype=torch.uint8, device=dev)
+    _gemm(lib, dev, _lib.EPI_BIAS, Ad, Wd, bd, out, K, scale_cols=64, scale=0.125)       # -> split16 rows
     ref = acc + bias.double()
     ref[:, :64] *= 0.125
-    assert_close(join(out, N), ref, et, et, "bias")
-    _gemm(lib, dev, _lib.EPI_BIAS_GELU, Ad, Wd, bd, out, K)
-    assert_close(join(out, N), O.gelu_erf(acc + bias.double()), 2.5e-5, et, "gelu")   # polynomial erf: 1.2e-5
+    assert_close(join16(out.view(torch.float16), N), ref, ea, er, "bias")
+    _gemm(lib, dev, _lib.EPI_BIAS_GELU, Ad, Wd, bd, out, K)                                  # -> split8 rows
+    assert_close(join8(out, N), O.gelu_erf(acc + bias.double()), ea, er + 2.0 ** -14, "gelu")
     x0 = synth.randn("t.g.x", (M, N), 2.0, 2)
     xd = x0.to(dev)
     _gemm(lib, dev, _lib.EPI_BIAS_RESID, Ad, Wd, bd, xd, K)
-    assert_close(xd, x0.double() + acc + bias.double(), et, et, "resid")
+    assert_close(xd, x0.double() + acc + bias.double(), ea, er, "resid")
     o32 = torch.empty(M, N, dtype=torch.float32, device=dev)
     _gemm(lib, dev, _lib.EPI_ACT_F32, Ad, Wd, None, o32, K, act=1)
-    assert_close(o32, O.leaky_relu(acc), et, et, "leaky")
+    assert_close(o32, O.leaky_relu(acc), ea, er, "leaky")
+    # a weight that is exact in fp16 (its lo plane is all zero): same function of the rounded weight.  (The 3-plane
+    # 'exact' form, which skips the weight-lo tile, is selected by aaclip_block_weights.exact16 and is exercised by
+    # test_full_b4_fp16_native_weights; the generic aaclip_gemm entry point always takes 4-plane weights.)
+    Wh = W.half().float()
+    W4 = engine.split_rows(Wh.to(dev), weight=True)
+    _gemm(lib, dev, _lib.EPI_ACT_F32, Ad, W4, None, o32, K)
+    assert_close(o32, A.double() @ Wh.double().t(), ea, er, "fp16-exact weight, 4 planes")
 
 
 def _attn_ref(qkv, B, L, H, causal):
@@ -147,15 +193,15 @@ def test_attention_split(dev, cfg, log2q):
     D = H * 64
     qkv = synth.randn("t.attn", (B * L, 3 * D), 1.0, 3)
     qkv[:, :D] *= 0.6 * (1.4426950408889634 if log2q else 1.0)
-    qd = engine.split_rows(qkv.to(dev))
-    ctx = torch.full((B * L, 2 * D), float("nan"), dtype=torch.float16, device=dev)
+    qd = engine.split16_rows(qkv.to(dev))
+    ctx = torch.full((B * L, 4 * D), 0xAA, dtype=torch.uint8, device=dev)      # split8 rows out
     fn = lib.aaclip_attention_log2q if log2q else lib.aaclip_attention
     _lib.check(fn(F16X2, qd.data_ptr(), ctx.data_ptr(), B, L, H, causal, stream(dev)), "attention")
     f = qkv.clone()
     if log2q:
         f[:, :D] *= 0.6931471805599453
     ref = _attn_ref(f, B, L, H, causal)
-    assert_close(join(ctx, D), ref, 4e-4, 1e-3, f"attention split {cfg}")
+    assert_close(join8(ctx, D), ref, 4e-4, 1e-3, f"attention split {cfg}")
 
 
 @pytest.mark.parametrize("code", [F16, F16X2])
@@ -178,11 +224,11 @@ def test_attention_first_tile_far_below_zero(dev, code, L, causal):
         ctx = torch.full((L, D), float("nan"), dtype=torch.float16, device=dev)
         ref_in = q.float()
     else:
-        qd = engine.split_rows(qkv.to(dev))
-        ctx = torch.full((L, 2 * D), float("nan"), dtype=torch.float16, device=dev)
+        qd = engine.split16_rows(qkv.to(dev))
+        ctx = torch.full((L, 4 * D), 0xAA, dtype=torch.uint8, device=dev)
         ref_in = qkv.clone()
     _lib.check(lib.aaclip_attention_log2q(code, qd.data_ptr(), ctx.data_ptr(), 1, L, H, causal, stream(dev)))
     ref_in[:, :64] *= 0.6931471805599453
     ref = _attn_ref(ref_in, 1, L, H, causal)
-    got = ctx.float() if code == F16 else join(ctx, D)
+    got = ctx.float() if code == F16 else join8(ctx, D)
     assert_close(got, ref, 3e-3 if code == F16 else 4e-4, 1e-2, f"first tile -150, L={L}, causal={causal}")
