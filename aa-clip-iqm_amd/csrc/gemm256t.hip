@@ -983,6 +983,50 @@ __global__ __launch_bounds__(512, 2) void gemm16_256w_kernel(GemmParams p, int P
 // NP = 0: plain 16-bit operands; NP = 4 / 3: split8 operands (common.h): per pair of K tiles two fp16 tiles and two
 // (one: weight exact in fp16) e4m3 correction tiles, all through the same phases; a phase of an e4m3 tile issues 8
 // 16x16x128 block-scaled MFMAs (32 cycles each) where an fp16 tile issues 16 16x16x32 ones (16 cycles each)
+// The two 16-byte fragments (k-steps) of one 16-row tile.  Plain operands: two independent 4-register values, as the
+// kernel always had them.  Split8 operands: ONE 8-register value, because the block-scaled e4m3 MFMA takes both
+// fragments as a single 32-byte operand -- kept separate, hipcc copies them into fresh 8-register tuples for every MFMA
+// and spills (61-201 registers); the fp16 MFMAs of the same kernel read the halves as sub-registers.
+template <typename T, bool WIDE> struct FragPair {
+  typename Elem<T>::vec8 h[2];
+  AACLIP_DEV typename Elem<T>::vec8 get(int ks) const { return h[ks]; }
+  AACLIP_DEV void set(int ks, typename Elem<T>::vec8 v) { h[ks] = v; }
+};
+template <> struct FragPair<f16, true> {
+  i32x8 v;
+  AACLIP_DEV f16x8 get(int ks) const {
+    const i32x4 x = {v[4 * ks], v[4 * ks + 1], v[4 * ks + 2], v[4 * ks + 3]};
+    return __builtin_bit_cast(f16x8, x);
+  }
+  AACLIP_DEV void set(int ks, f16x8 f) {
+    const i32x4 x = __builtin_bit_cast(i32x4, f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * ks + e] = x[e];
+  }
+};
+AACLIP_DEV f32x4 mma_e4m3w(const FragPair<f16, true>& a, const FragPair<f16, true>& b, f32x4 c, int sa, int sb) {
+  // inline asm with the accumulator tied in place: through the builtin hipcc gives many of these MFMAs a destination
+  // tuple different from their C operand (copies back, spills).  No result of a correction tile is read before the
+  // next s_barrier, so no wait states are needed here; the epilogue waits (see the end of the K loop).
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+               : "+v"(c) : "v"(a.v), "v"(b.v), "v"(sa), "v"(sb));
+  return c;
+}
+// The same with both scale bytes taken from ONE register (the kernel is at its register limit): `sc` holds
+// [byte 0: T1 act, byte 1: T1 weight, byte 2: T2 weight, byte 3: T2 act]; op_sel / op_sel_hi pick the byte per operand.
+template <int KIND>
+AACLIP_DEV f32x4 mma_e4m3k(const FragPair<f16, true>& w, const FragPair<f16, true>& a, f32x4 c, int sc) {
+  if (KIND == 1)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel:[1,0,0] op_sel_hi:[0,0,0]"
+                 : "+v"(c) : "v"(w.v), "v"(a.v), "v"(sc));
+  else
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]"
+                 : "+v"(c) : "v"(w.v), "v"(a.v), "v"(sc));
+  return c;
+}
+template <int KIND, typename T> AACLIP_DEV f32x4 mma_e4m3k(const FragPair<T, false>&, const FragPair<T, false>&, f32x4 c, int) { return c; }
+template <typename T> AACLIP_DEV f32x4 mma_e4m3w(const FragPair<T, false>&, const FragPair<T, false>&, f32x4 c, int, int) { return c; }
+
 template <typename T, int EPI, int NP = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
@@ -1026,7 +1070,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
       int row, chunk;
       tile_src_id(ga * 64 + lane, row, chunk);
       int ar = tm * 256 + row;
-      ar = ar < p.M ? ar : p.M - 1;
+      // plain operands: rows past M re-read row M - 1.  Split operands: no clamp -- the buffer descriptor ends with the
+      // matrix and reads past it return zero (see rsA), so the second half's offsets are the first half's plus a
+      // wave-uniform constant and need no registers (this kernel has none to spare: a spilled address is reloaded
+      // with scratch_load + s_waitcnt vmcnt(0) in front of a DMA, which drains the whole DMA pipeline once per tile)
+      if (NP == 0) ar = ar < p.M ? ar : p.M - 1;
       srcA[sub][j] = ((ar - tm * 256) * (int)p.lda + chunk * 8) * 2;
       dstA[sub][j] = ga * 1024;
       tile_src_id(gw * 64 + lane, row, chunk);
@@ -1038,7 +1086,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   // added and the residual GEMMs ran 15 % slower with an unchanged K loop in source
   const T* baseA = uniform_ptr((const T*)p.A + (long)tm * 256 * p.lda);
   const T* baseW = uniform_ptr((const T*)p.W + (long)tn * 256 * ldw);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7FFFFFF0, 0x00020000);
+  // split operands: num_records = the bytes from this tile's first row to the end of A (out-of-range rows read as zero)
+  const long bytesA = ((long)p.M - (long)tm * 256) * p.lda * 2;
+  const int recA = NP == 0 ? 0x7FFFFFF0 : (int)(bytesA < 0x7FFFFFF0L ? bytesA : 0x7FFFFFF0L);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, __builtin_amdgcn_readfirstlane(recA), 0x00020000);
+  const int subA = 64 * (int)p.lda * 2, subW = 32 * ldw * 2;   // bytes from a DMA piece of half 0 to the same piece of half 1
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
   int offM[2][2], offN[2][2];   // [ks][tile parity]
 #pragma unroll
@@ -1058,7 +1110,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   // LayerNorm folding: this lane's (rstd, -mean*rstd) pairs, requested now so that they are there at the epilogue
   f32x2 ab_pre[8];
-  const bool fold_pre = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.row_ab != nullptr;
+  const bool fold_pre = NP == 0 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.row_ab != nullptr;
   if (fold_pre) {
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -1069,33 +1121,44 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   }
 
   const int nk = vtile_count<NP>(p.K);   // (virtual) K tiles
+  // e8m0 scale bytes of the correction tiles (stored operand = value * 2^EXP): T1 act | T1 weight | T2 weight | T2 act
+  int sc_pack = (127 - SPLIT8_ACT_LO_EXP) | ((127 - SPLIT8_W_HI_EXP) << 8) | ((127 - SPLIT8_W_LO_EXP) << 16) |
+                ((127 - SPLIT8_ACT_HI_EXP) << 24);
+  (void)sc_pack;
 #define DMA(rs, src, dst, st, so) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (st) * 65536 + dst), 16, src, so, 0, 0);
-#define GA(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd); DMA(rsA, srcA[sub][0], dstA[sub][0], st, so) DMA(rsA, srcA[sub][1], dstA[sub][1], st, so) }
-#define GW(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd); DMA(rsW, srcW[sub][0], dstW[sub][0], st, so) DMA(rsW, srcW[sub][1], dstW[sub][1], st, so) }
+#define GA(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd) + (NP != 0 ? (sub) * subA : 0); \
+    DMA(rsA, srcA[NP != 0 ? 0 : (sub)][0], dstA[sub][0], st, so) DMA(rsA, srcA[NP != 0 ? 0 : (sub)][1], dstA[sub][1], st, so) }
+#define GW(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd) + (NP != 0 ? (sub) * subW : 0); \
+    DMA(rsW, srcW[NP != 0 ? 0 : (sub)][0], dstW[sub][0], st, so) DMA(rsW, srcW[NP != 0 ? 0 : (sub)][1], dstW[sub][1], st, so) }
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define BAR __builtin_amdgcn_s_barrier();
 #define PINB __builtin_amdgcn_sched_barrier(0);
+// Split kernels (no register to spare, see srcA): the offset of the odd 16-row tile is recomputed from the even one
+// at every use -- 16 rows further = 8 row pairs = 2048 bytes, and the swizzle's bit 3 flips: (off ^ 128) + 2048.  The
+// xor goes through an opaque asm so that hipcc does not hoist it back into a loop-invariant register.
+#define ODD_OFF(off) ({ int o_; asm volatile("v_xor_b32 %0, 0x80, %1" : "=v"(o_) : "v"(off)); o_ + 2048; })
 #define LD_M(sb, a)                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) \
-      fm[t][ks] = *(const vec8*)((sb) + offM[ks][t & 1] + ((a) * 2 + (t >> 1)) * 4096);
+      fm[t].set(ks, *(const vec8*)((sb) + ((NP != 0 && (t & 1)) ? ODD_OFF(offM[ks][0]) : offM[ks][t & 1]) + ((a) * 2 + (t >> 1)) * 4096));
 #define LD_N(FN, sb, b)                                                                     \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 2; ++t) \
-      FN[t][ks] = *(const vec8*)((sb) + offN[ks][t] + (b) * 4096);
-#define MM(FN, a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(FN[u][ks], fm[t][ks], acc[4 * (a) + (t)][2 * (b) + (u)]);
+      FN[t].set(ks, *(const vec8*)((sb) + ((NP != 0 && t == 1) ? ODD_OFF(offN[ks][0]) : offN[ks][t]) + (b) * 4096));
+#define MM(FN, a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(FN[u].get(ks), fm[t].get(ks), acc[4 * (a) + (t)][2 * (b) + (u)]);
 // e4m3 tile: the two 16-byte fragments of a row are one 32-byte operand (common.h, mma_e4m3); W rows are the MFMA's A side
-#define MM8(FN, a, b, t, u) acc[4 * (a) + (t)][2 * (b) + (u)] = mma_e4m3(FN[u][0], FN[u][1], fm[t][0], fm[t][1], acc[4 * (a) + (t)][2 * (b) + (u)], sc_w, sc_a);
-#define QUADX(FN, a, b)                                                                      \
+#define MM8(FN, a, b, t, u, KIND) acc[4 * (a) + (t)][2 * (b) + (u)] = mma_e4m3k<(KIND) == 1 ? 1 : 2>(FN[u], fm[t], acc[4 * (a) + (t)][2 * (b) + (u)], sc_pack);
+// KIND is a literal (0 fp16 tile, 1 / 2 e4m3 correction tiles): the K loop is unrolled over one period of the tile
+// kinds, so no branch surrounds the MFMAs -- with a run-time branch the accumulators of the two arms meet in phi
+// nodes hipcc does not coalesce (results in fresh registers + 472 v_mov + 200 spilled registers, 4x slower)
+#define QUADX(FN, a, b, KIND)                                                                \
   {                                                                                          \
     LGKM0                                                                                    \
     PINB                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                           \
-    if (NP != 0 && kind != 0) {                                                              \
-      if constexpr (NP != 0) {                                                               \
-        MM8(FN, a, b, 0, 0) MM8(FN, a, b, 0, 1) MM8(FN, a, b, 1, 0) MM8(FN, a, b, 1, 1)      \
-        MM8(FN, a, b, 2, 0) MM8(FN, a, b, 2, 1) MM8(FN, a, b, 3, 0) MM8(FN, a, b, 3, 1)      \
-      }                                                                                      \
+    if ((KIND) != 0) {                                                                       \
+      MM8(FN, a, b, 0, 0, KIND) MM8(FN, a, b, 0, 1, KIND) MM8(FN, a, b, 1, 0, KIND) MM8(FN, a, b, 1, 1, KIND) \
+      MM8(FN, a, b, 2, 0, KIND) MM8(FN, a, b, 2, 1, KIND) MM8(FN, a, b, 3, 0, KIND) MM8(FN, a, b, 3, 1, KIND) \
     } else {                                                                                 \
     MM(FN, a, b, 0, 0, 0) MM(FN, a, b, 0, 1, 0) MM(FN, a, b, 1, 0, 0) MM(FN, a, b, 1, 1, 0)  \
     MM(FN, a, b, 2, 0, 0) MM(FN, a, b, 2, 1, 0) MM(FN, a, b, 3, 0, 0) MM(FN, a, b, 3, 1, 0)  \
@@ -1106,56 +1169,70 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     PINB                                                                                     \
   }
 // one K tile: FB0 holds B0(kt) on entry; FB1 receives B1(kt) and then B0(kt+1)
-#define KTILE(kt, FB0, FB1)                                                                   \
+#define KTILE(kt, FB0, FB1, KIND)                                                             \
   {                                                                                           \
     const int cur = (kt) & 1, nxt = cur ^ 1;                                                  \
     const bool more1 = (kt) + 1 < nk, more2 = (kt) + 2 < nk;                                  \
-    int kind;                                                                                 \
-    (void)vtile_off<NP>(kt, p.K, kind);                                                       \
-    const int sc_w = vtile_scale_w(kind), sc_a = vtile_scale_act(kind);                       \
-    (void)sc_w; (void)sc_a;                                                                   \
     const char* sb = smem + cur * 65536;                                                      \
     /* P0: confirm B1(kt); read A0(kt); issue A0(kt+1) */                                     \
     if (more1) WAIT_VM(4); else WAIT_VM(2);                                                   \
     LD_M(sb, 0)                                                                               \
     if (more1) GA(0, nxt, (kt) + 1)                                                           \
     BAR                                                                                       \
-    QUADX(FB0, 0, 0)                                                                          \
+    QUADX(FB0, 0, 0, KIND)                                                                          \
     BAR                                                                                       \
     /* P1: confirm A1(kt); read B1(kt); issue B1(kt+1) */                                     \
     if (more1) WAIT_VM(4); else WAIT_VM(0);                                                   \
     LD_N(FB1, sb, 1)                                                                          \
     if (more1) GW(1, nxt, (kt) + 1)                                                           \
     BAR                                                                                       \
-    QUADX(FB1, 0, 1)                                                                          \
+    QUADX(FB1, 0, 1, KIND)                                                                          \
     BAR                                                                                       \
     /* P2: confirm B0(kt+1); read A1(kt); issue A1(kt+1) */                                   \
     if (more1) WAIT_VM(4);                                                                    \
     LD_M(sb, 1)                                                                               \
     if (more1) GA(1, nxt, (kt) + 1)                                                           \
     BAR                                                                                       \
-    QUADX(FB1, 1, 1)                                                                          \
+    QUADX(FB1, 1, 1, KIND)                                                                          \
     BAR                                                                                       \
     /* P3: confirm A0(kt+1); read B0(kt+1) into the set B1 vacated; issue B0(kt+2) */         \
     if (more1) WAIT_VM(4);                                                                    \
     if (more1) LD_N(FB1, smem + nxt * 65536, 0)                                               \
     if (more2) GW(0, cur, (kt) + 2)                                                           \
     BAR                                                                                       \
-    QUADX(FB0, 1, 0)                                                                          \
+    QUADX(FB0, 1, 0, KIND)                                                                          \
     BAR                                                                                       \
   }
 
   // prologue: B0, A0, B1, A1 of tile 0 and B0 of tile 1; B0(0) in registers, A0(0) confirmed
   GW(0, 0, 0) GA(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
   if (nk > 1) GW(0, 1, 1)
-  vec8 fm[4][2], fnX[2][2], fnY[2][2];
+  FragPair<T, NP != 0> fm[4], fnX[2], fnY[2];
   if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
   BAR
   LD_N(fnX, smem, 0)
   if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
-  for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
-    KTILE(kt, fnX, fnY)
-    KTILE(kt + 1, fnY, fnX)
+  if constexpr (NP == 0) {
+    for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
+      KTILE(kt, fnX, fnY, 0)
+      KTILE(kt + 1, fnY, fnX, 0)
+    }
+  } else if constexpr (NP == 4) {          // per pair of K tiles: fp16, fp16, Al8.Wh8, Ah8.Wl8
+    for (int kt = 0; kt < nk; kt += 4) {
+      KTILE(kt, fnX, fnY, 0)
+      KTILE(kt + 1, fnY, fnX, 0)
+      KTILE(kt + 2, fnX, fnY, 1)
+      KTILE(kt + 3, fnY, fnX, 2)
+    }
+  } else {                                 // weight exact in fp16: fp16, fp16, Al8.Wh8; two periods per trip
+    for (int kt = 0; kt < nk; kt += 6) {   // (K is a multiple of 256: checked by the launcher)
+      KTILE(kt, fnX, fnY, 0)
+      KTILE(kt + 1, fnY, fnX, 0)
+      KTILE(kt + 2, fnX, fnY, 1)
+      KTILE(kt + 3, fnY, fnX, 0)
+      KTILE(kt + 4, fnX, fnY, 0)
+      KTILE(kt + 5, fnY, fnX, 1)
+    }
   }
   if (wr == 0) BAR   // balance the barrier count of the two groups
 #undef DMA
@@ -1166,6 +1243,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef BAR
 #undef PINB
 #undef LD_M
+#undef ODD_OFF
 #undef LD_N
 #undef MM
 #undef MM8
