@@ -172,9 +172,9 @@ def main(argv=None):
     parser.add_argument("--iqm_num_layers", type=int, default=2)
     parser.add_argument("--iqm_num_heads", type=int, default=8)
     parser.add_argument("--iqm_weight", type=float, default=0.7)
-    parser.add_argument("--precision", type=str, default="fp16",
-                        help="fp32 (exact), fp16x2 (split fp16 on the 16-bit MFMAs: inside 1e-3 + 1e-2 of fp32 on maps), "
-                             "fp16 (fastest; maps up to ~3x outside that tolerance) or bf16")
+    parser.add_argument("--precision", type=str, default="fp16x2",
+                        help="fp16x2 (default: split fp16 on the 16-bit MFMAs, inside 1e-3 + 1e-2 of the fp32 reference on "
+                             "taps and maps), fp32 (exact), fp16 (fastest; maps up to ~3x outside that tolerance) or bf16")
     parser.add_argument("--device_preprocess", action="store_true", help="resize + normalise on the GPU")
     parser.add_argument("--iqm", choices=["on", "off"], default="on",
                         help="on: maps = 0.6 text + 0.4 IQM like the reference; off: text-only branch")

@@ -45,10 +45,11 @@ GFLOP_TOWER = 1013.6   # visual tower only, per image
 GFLOP_FULL = 1041.6    # + adapters, seg/det proj, map
 PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0}   # MI355X_MICROARCH.md, dense
 DTYPE_NAME = {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "fp16x2": "f16x2"}
-# fp16x2 (split fp16, include/aaclip.h AACLIP_F16X2): every matrix product issues 3 fp16 MFMA products (2 where the
-# weight is exact in fp16).  Rates and roofline fractions count the ALGORITHMIC flops (1013.6 GFLOP per image) against
-# the fp16 MFMA peak; the MFMA pipe does `mfma_multiple` times that work.
-MFMA_MULTIPLE = {"fp16": 1, "bf16": 1, "fp32": 1, "fp16x2": 3}
+# fp16x2 (split fp16, include/aaclip.h AACLIP_F16X2): a GEMM accumulates the fp16 product plus two correction products on
+# the block-scaled e4m3 MFMAs (twice the fp16 rate): 2.0 fp16-MFMA time units per algorithmic unit, 1.5 where the weight
+# is exact in fp16 (one correction product); attention: 3 + 2 fp16 products = 2.5 units.  Rates and roofline fractions
+# count the ALGORITHMIC flops (1013.6 GFLOP per image) against the fp16 MFMA peak; the MFMA pipe is busy
+# `mfma_time_multiple` times as long as those flops alone would keep it.
 TAGS = {0: "layernorm", 1: "qkv_gemm", 2: "attention", 3: "out_proj_gemm", 4: "c_fc_gemm", 5: "c_proj_gemm",
         6: "adapter"}
 
@@ -59,7 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "fp16x2"])
+    # default = the fastest arithmetic mode that meets BASELINE.json's tolerance (1e-3 abs + 1e-2 rel vs the fp32
+    # reference) on every output; plain fp16 is ~2x faster and up to ~3x outside it on taps and maps (`fp16_companion`)
+    ap.add_argument("--precision", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp32"])
     ap.add_argument("--clip-weights", default="fp32", choices=["fp32", "fp16"],
                     help="synthetic CLIP weights as drawn (fp32) or rounded through fp16 like OpenAI's stored checkpoint "
                          "(fp16x2 then skips the weight-lo product of those matrices: 2 MFMA products instead of 3)")
@@ -289,6 +292,16 @@ def run_rank(args):
                         extra[f"{other_p}_companion"] = companion(other_p, build, args, B, dev, torch)
                     except Exception as e:   # noqa: BLE001
                         extra[f"{other_p}_companion"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                if args.precision == "fp16x2" and args.clip_weights == "fp32":
+                    # the deployment case: CLIP weights exact in fp16 (OpenAI's checkpoint is stored in fp16), for which
+                    # the weight-lo correction product is skipped
+                    try:
+                        args.clip_weights = "fp16"
+                        extra["fp16x2_fp16_exact_clip_weights"] = companion("fp16x2", build, args, B, dev, torch)
+                    except Exception as e:   # noqa: BLE001
+                        extra["fp16x2_fp16_exact_clip_weights"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    finally:
+                        args.clip_weights = "fp32"
         if dist is not None:
             dist.barrier()
 
@@ -341,7 +354,7 @@ def run_rank(args):
             tname = DTYPE_NAME[args.precision]
             kname = {"fp32": "gemm32_kernel<EPI_BIAS_GELU>",
                      "fp16x2": "gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP=%d>" % (
-                         2 if args.clip_weights == "fp16" else 3)}.get(
+                         3 if args.clip_weights == "fp16" else 4)}.get(
                              args.precision, f"gemm16_256x_kernel<{tname}, EPI_BIAS_GELU>")
             result.update({
                 "whole_path_tflops": round(value * gflop_img / 1e3, 1),
@@ -357,7 +370,7 @@ def run_rank(args):
                     "launches_timed": len(fc_ms),
                     "avg_launch_ms": round(fc_avg, 4),
                     "flop_per_launch": fc_flop,
-                    "mfma_multiple": (2 if args.clip_weights == "fp16" else 3) if args.precision == "fp16x2" else 1,
+                    "mfma_time_multiple": (1.5 if args.clip_weights == "fp16" else 2.0) if args.precision == "fp16x2" else 1.0,
                 },
                 "parity_vs_north_star": parity_fields(args.precision),
             })

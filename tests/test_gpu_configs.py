@@ -176,12 +176,13 @@ def test_full_b4_encode_image_taps_vs_reference_golden(dev, g4, weights, code):
     compare(f"{tag}.b4.pooled", pooled, T(g4["full4.pooled"]), *TAP_TOL[code])
 
 
-def test_config2_b64_encode_image_is_the_b4_result(dev, g4, weights):
-    """BASELINE config 2 at its size: encode_image(img64, [6,12,18,24]), fp16.  Images 0..3 are the golden B = 4
-    images; every tap row and pooled row of theirs must be BIT-IDENTICAL to the B = 4 run (same kernels, rows are
-    independent), which test_full_b4_encode_image_taps_vs_reference_golden pins to the reference.  Two runs are
-    bit-identical; all 64 results are finite and differ between images."""
-    model = build(dev, "fp16", weights)
+@pytest.mark.parametrize("code", [F16X2, F16])
+def test_config2_b64_encode_image_is_the_b4_result(dev, g4, weights, code):
+    """BASELINE config 2 at its size: encode_image(img64, [6,12,18,24]), in the benchmarked mode (fp16x2) and in plain
+    fp16.  Images 0..3 are the golden B = 4 images; every tap row and pooled row of theirs must be BIT-IDENTICAL to
+    the B = 4 run (same kernels, rows are independent), which test_full_b4_encode_image_taps_vs_reference_golden pins
+    to the reference.  Two runs are bit-identical; all 64 results are finite and differ between images."""
+    model = build(dev, NAME[code], weights)
     img4 = images4(g4)
     img64 = torch.cat([img4, synth.synth_images(60, 518, seed=64)], dim=0).to(dev)
     with torch.no_grad():
@@ -196,14 +197,15 @@ def test_config2_b64_encode_image_is_the_b4_result(dev, g4, weights):
         assert torch.isfinite(a).all()
     assert float((p64[5] - p64[6]).abs().max()) > 1e-3
     a, b = sampled(g4, "full4.tap24", t64[3][:4])
-    compare("fp16.b64.tap24_first4", a, b, *TAP_TOL[F16])
+    compare(f"{NAME[code]}.b64.tap24_first4", a, b, *TAP_TOL[code])
 
 
-def test_config3_b64_full_path_is_the_b4_result(dev, g4, weights):
-    """BASELINE config 3 at its size: AdaptedCLIP.forward + fused anomaly map at B = 64, fp16; images 0..3 are
-    bit-identical to the B = 4 run that is pinned to the reference golden."""
+@pytest.mark.parametrize("code", [F16X2, F16])
+def test_config3_b64_full_path_is_the_b4_result(dev, g4, weights, code):
+    """BASELINE config 3 at its size: AdaptedCLIP.forward + fused anomaly map at B = 64 (fp16x2 and fp16); images 0..3
+    are bit-identical to the B = 4 run that is pinned to the reference golden."""
     import forward_utils as FU
-    model = build(dev, "fp16", weights)
+    model = build(dev, NAME[code], weights)
     img64 = torch.cat([images4(g4), synth.synth_images(60, 518, seed=64)], dim=0).to(dev)
     anchors = T(np.load(os.path.join(GOLDEN, "full.npz"))["full.anchors_bottle"]).to(dev)
     with torch.no_grad():
@@ -216,10 +218,10 @@ def test_config3_b64_full_path_is_the_b4_result(dev, g4, weights):
     assert torch.equal(det[:4], det4) and torch.equal(m64[:4], m4)
     assert m64.shape == (64, 518, 518) and torch.isfinite(m64).all()
     a, b = sampled(g4, "full4.seg3", seg[3][:4])
-    compare("fp16.b64.seg3_first4", a, b, *FEATURE_TOL[F16])
+    compare(f"{NAME[code]}.b64.seg3_first4", a, b, *FEATURE_TOL[code])
 
 
-@pytest.mark.parametrize("code", [F16, BF16])
+@pytest.mark.parametrize("code", [F16X2, F16, BF16])
 def test_config5_b128_four_tap_layers(dev, g4, weights, code):
     """BASELINE config 5: 16-bit MFMA path, batch 128 per GPU, multi-layer patch-feature extraction (4 tap layers).
     Size-independent properties: images 0..3 bit-identical to the B = 4 run of the same dtype, run-to-run
@@ -239,9 +241,9 @@ def test_config5_b128_four_tap_layers(dev, g4, weights, code):
         assert a.shape == (128, 1369, 768) and torch.equal(a[:4], b)
     assert torch.equal(det[:4], det4)
     assert float((p[100] - p[101]).abs().max()) > 1e-3
-    if code == F16:
+    if code in (F16, F16X2):
         a, b = sampled(g4, "full4.tap18", t[2][:4])
-        compare("fp16.b128.tap18_first4", a, b, *TAP_TOL[F16])
+        compare(f"{NAME[code]}.b128.tap18_first4", a, b, *TAP_TOL[code])
     else:   # bf16: 8-bit mantissa, offered, not the parity path
         a, b = sampled(g4, "full4.seg3", seg[3][:4])
         compare("bf16.b128.seg3_first4", a, b, 1e-2, 5e-2)

@@ -296,8 +296,10 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
                            "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     checked = 0
-    # NP = 0: plain fp16 operands; NP = 3 / 2: the split-fp16 instantiations (virtual K tiles, run-time tile offsets)
-    for epi, np_ in [(e, n) for n in (0, 3, 2) for e in range(5)]:
+    # NP = 0: plain fp16 operands; NP = 4 / 3: the split-fp16 instantiations (virtual K tiles, run-time tile offsets).
+    # For those a spill is worse than slow: a spilled address comes back through scratch_load + s_waitcnt vmcnt(0),
+    # which drains the DMA pipeline once per tile (measured: 1.60 -> 1.35 ms per c_fc launch when the last one went).
+    for epi, np_ in [(e, n) for n in (0, 4, 3) for e in range(5)]:
         sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}ELi{np_}EEEvNS_10GemmParamsEiiiii:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
