@@ -44,7 +44,8 @@ template <typename T> AACLIP_DEV float to_float(T v) { return (float)v; }
 // A value v is carried as hi = fp16(v) plus a correction for v - hi, so that a product sees ~15-21 bits of each operand
 // instead of 11.  Two row formats (logical width C, 4 bytes per element, row stride >= 2C halves):
 //   split16 row  [hi: C x fp16][lo: C x fp16]                    lo = fp16(v - hi).  Attention inputs (q | k | v): the
-//                attention kernel runs q.k^T as Kh.Qh + Kl.Qh + Kh.Ql and p.v as Vh.P + Vl.P on the fp16 MFMAs.
+//                attention kernel runs q.k^T as Kh.Qh + Kl.Qh + Kh.Ql and p.v as Vh.P on the fp16 MFMAs (v's lo half
+//                is not used: attention.hip says why).
 //   split8 row   [hi: C x fp16][lo8: C x e4m3][hi8: C x e4m3]    lo8 = e4m3((v - hi) * 2^10), hi8 = e4m3(v).  GEMM
 //                A operands.  Weights likewise: [Wh: K x fp16][Wh8 = e4m3(W * 2^6)][Wl8 = e4m3((W - Wh) * 2^17)]
 //                (the last plane is absent when the weight is exact in fp16).  A product over K is accumulated as

@@ -15,6 +15,7 @@ ap.add_argument("--H", type=int, default=16)
 ap.add_argument("--causal", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0, help="1 = force the 128-row kernel")
 ap.add_argument("--scale", type=float, default=0.5)
+ap.add_argument("--split", action="store_true", help="the split-fp16 kernel (AACLIP_F16X2): split16 rows in, split8 rows out")
 ap.add_argument("--plain", action="store_true", help="time the plain contract (aaclip_attention: natural-exp scores, a per-score "
                 "multiply) instead of the kernel variant the block path runs (aaclip_attention_log2q)")
 a = ap.parse_args()
@@ -25,12 +26,18 @@ B, L, H = a.batch, a.L, a.H
 D = 64 * H
 qkv = torch.randn(B * L, 3 * D, device=dev)
 qkv[:, :D] *= a.scale
-qkv = qkv.half()
-ctx = torch.empty(B * L, D, device=dev, dtype=torch.float16)
+if a.split:
+    from aaclip_hip import engine
+    qkv = engine.split16_rows(qkv)
+    ctx = torch.empty(B * L, 4 * D, device=dev, dtype=torch.uint8)
+else:
+    qkv = qkv.half()
+    ctx = torch.empty(B * L, D, device=dev, dtype=torch.float16)
+code = _lib.F16X2 if a.split else _lib.F16
 st = torch.cuda.current_stream().cuda_stream
 fn = lib.aaclip_attention if a.plain else lib.aaclip_attention_log2q   # same scores either way: random q
 def run():
-    _lib.check(fn(_lib.F16, qkv.data_ptr(), ctx.data_ptr(), B, L, H, a.causal, st))
+    _lib.check(fn(code, qkv.data_ptr(), ctx.data_ptr(), B, L, H, a.causal, st))
 run(); torch.cuda.synchronize()
 fl = 4.0 * B * H * L * L * 64 * (0.5 if a.causal else 1.0)
 ts = []
