@@ -14,16 +14,27 @@
  *  - `dtype` selects the arithmetic type of the matrix products:
  *      AACLIP_F32  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), parity path
  *      AACLIP_F16 / AACLIP_BF16  16-bit operands, fp32 accumulate (v_mfma_f32_32x32x16)
- *      AACLIP_F16X2  split fp16: every matrix-product operand is carried as hi = fp16(v) plus lo = fp16(v - hi)
- *                    (~21 significant bits) and every product A.W^T is accumulated as Ah.Wh^T + Al.Wh^T + Ah.Wl^T
- *                    on the fp16 MFMAs into one fp32 accumulator (attention: 3 products for q.k^T, 2 for p.v with p
- *                    rounded to fp16 once).  The mode that meets 1e-3 abs + 1e-2 rel against the fp32 reference on
- *                    taps and anomaly maps at MFMA speed.  A split row of logical width C is stored as C hi halves
- *                    followed by C lo halves (4 bytes per element, row stride >= 2C halves); this holds for weights
- *                    ([out, 2*in]), for the 16-bit inputs / outputs of aaclip_gemm and for the packed q|k|v and
- *                    context rows of aaclip_attention.  A weight whose values are exact in fp16 (OpenAI's CLIP
- *                    checkpoints are stored in fp16) may be passed as plain fp16 [out, in] where an `exact16` flag
- *                    exists (aaclip_block_weights): the Ah.Wl^T product is then skipped.
+ *      AACLIP_F16X2  split fp16: every matrix-product operand is carried as hi = fp16(v) plus a correction for v - hi
+ *                    and a product is accumulated into one fp32 accumulator as main term + correction terms -- the mode
+ *                    that meets 1e-3 abs + 1e-2 rel against the fp32 reference on taps and anomaly maps at MFMA speed.
+ *                    GEMMs: A.W^T = Ah.Wh^T (fp16 MFMA) + Al8.Wh8^T + Ah8.Wl8^T (block-scaled e4m3 MFMA,
+ *                    v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate; the corrections are 2^-11 of the main
+ *                    term, so 4 significant bits in them leave ~2^-15 per operand).  Attention: q.k^T = Kh.Qh + Kl.Qh
+ *                    + Kh.Ql on the fp16 MFMAs, p.v with p and v in fp16.  Row formats, 4 bytes per element, row
+ *                    strides counted in halves (>= 2C for a logical width C):
+ *                      split8  [hi: C x fp16][lo8: C x e4m3 = (v - hi) * 2^10][hi8: C x e4m3 = v]
+ *                              the A operand of aaclip_gemm, the context rows aaclip_attention writes, the output of
+ *                              AACLIP_EPI_BIAS_GELU and of aaclip_layernorm(out_dtype = AACLIP_F16X2);
+ *                              weights [out, in] likewise: [Wh: in x fp16][e4m3(W * 2^6)][e4m3((W - Wh) * 2^17)]
+ *                      split16 [hi: C x fp16][lo: C x fp16 = v - hi]
+ *                              the packed q|k|v rows aaclip_attention reads (C = 3 * H * 64) = the output of
+ *                              AACLIP_EPI_BIAS.
+ *                    e4m3 = OCP e4m3fn; the scales are fixed (activations 0.016 ... 448 and weights 2.4e-4 ... 7 keep
+ *                    >= 4 significant bits in their correction operands; beyond, that element's correction degrades
+ *                    towards plain fp16, never the main term).  A weight whose values are exact in fp16 (OpenAI's
+ *                    CLIP checkpoints are stored in fp16) and whose in_features is a multiple of 256 may be passed
+ *                    WITHOUT its last plane ([out, 3 * in] bytes) where an `exact16` flag exists
+ *                    (aaclip_block_weights): the Ah8.Wl8^T product is then skipped.  K must be a multiple of 128.
  *    Weights of matrix products are passed already converted to `dtype`, row-major
  *    [out_features, in_features] exactly like nn.Linear.weight.  LayerNorm
  *    parameters, biases, embeddings, the residual stream and all outputs are fp32.
@@ -91,8 +102,9 @@ typedef struct aaclip_block_weights {
   const void* qkv_w_fold;  /* [3D, D] dtype: in_proj_weight * ln_1.weight[None, :] */
   const float* qkv_fold_s; /* [3D] */
   const float* qkv_fold_b; /* [3D]: in_proj_bias + in_proj_weight @ ln_1.bias */
-  /* ABI version >= 4, AACLIP_F16X2 only (ignored otherwise): bit mask of the matrix weights above that are passed as
-   * PLAIN fp16 [out, in] because every value is exact in fp16 (lo half all zero); the others are split [out, 2*in]. */
+  /* ABI version >= 4, AACLIP_F16X2 only (ignored otherwise): bit mask of the matrix weights above that are passed in
+   * the 3-plane form (fp16 plane + e4m3 plane, 3 bytes per element) because every value is exact in fp16; the others
+   * carry all three planes (4 bytes per element). */
   unsigned exact16;
 } aaclip_block_weights;
 enum { AACLIP_EXACT16_QKV = 1, AACLIP_EXACT16_OUT = 2, AACLIP_EXACT16_FC = 4, AACLIP_EXACT16_PROJ = 8,

@@ -17,14 +17,14 @@ import pytest
 import torch
 
 from aaclip_hip import _lib, engine, synth
-from aaclip_hip._lib import BF16, F16, F32
+from aaclip_hip._lib import BF16, F16, F16X2, F32
 from conftest import GOLDEN, PARITY_ERRORS
 from oracle import aaclip_oracle as O
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 TDT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
-NAME = {F32: "fp32", F16: "fp16", BF16: "bf16"}
+NAME = {F32: "fp32", F16: "fp16", BF16: "bf16", F16X2: "fp16x2"}
 
 
 @pytest.fixture(scope="module")
@@ -49,7 +49,8 @@ def assert_close(a, b, atol, rtol, what=""):
                            f"max err {err.max().item():.3e} at ref {b.flatten()[err.argmax()].item():.3e}")
 
 
-TOL = {F32: (2e-4, 1e-3), F16: (1e-3, 1e-2), BF16: (1e-2, 5e-2)}
+# fp16x2 (fp16 main term + e4m3 correction terms): asserted 5x tighter than the north star on these small models
+TOL = {F32: (2e-4, 1e-3), F16: (1e-3, 1e-2), BF16: (1e-2, 5e-2), F16X2: (2e-4, 2e-3)}
 
 
 # ----------------------------------------------------------------------------
@@ -253,7 +254,7 @@ def build_tiny(dev, precision):
     return cfg, sd, ia, ta, clip.to(dev).eval(), model.to(dev).eval()
 
 
-@pytest.mark.parametrize("code", [F32, F16, BF16])
+@pytest.mark.parametrize("code", [F32, F16X2, F16, BF16])
 def test_tiny_clip_vs_reference_golden(dev, golden_tiny, code):
     """CLIP.encode_image / encode_text against outputs of the reference itself."""
     cfg, sd, ia, ta, clip, model = build_tiny(dev, NAME[code])
@@ -263,14 +264,34 @@ def test_tiny_clip_vs_reference_golden(dev, golden_tiny, code):
         pooled, taps = clip.encode_image(img, [1, 3])
         txt = clip.encode_text(T(golden_tiny["tiny.tokens"]).to(dev))
     # residual stream values are O(1..5): the north-star tolerance is relative there
-    s = 4 if code != F32 else 1
+    s = 4 if code in (F16, BF16) else 1
     assert_close(taps[0], T(golden_tiny["tiny.tap1"]), s * atol, rtol, "tap1")
     assert_close(taps[1], T(golden_tiny["tiny.tap3"]), s * atol, rtol, "tap3")
     assert_close(pooled, T(golden_tiny["tiny.pooled"]), s * atol, rtol, "pooled")
     assert_close(txt, T(golden_tiny["tiny.text"]), s * atol, rtol, "text")
 
 
-@pytest.mark.parametrize("code", [F32, F16, BF16])
+def test_tiny_fp16_exact_weights_take_the_three_plane_form(dev):
+    """fp16x2 with CLIP weights that are exact in fp16: the engine passes those matrices without their lo plane
+    (aaclip_block_weights.exact16) and the small-batch split kernel skips the weight-lo correction tile -- same
+    function of the rounded weights, checked against the fp64 oracle on the rounded weights."""
+    from aaclip_hip import engine as E
+    cfg, sd, ia, ta, clip, model = build_tiny(dev, "fp16x2")
+    sdh = {k: (v.half().float() if v.is_floating_point() else v) for k, v in sd.items()}
+    clip.load_state_dict(sdh, strict=True)
+    blk = clip.visual.transformer.resblocks[0]
+    w, refs = E.pack_block(blk, F16X2, None)
+    assert w.exact16 == 15                                  # qkv, out, fc, proj all exact and K % 256 == 0
+    assert E.CACHE.get(blk.mlp.c_fc.weight, F16X2, "plain+exact").shape[1] == 3 * blk.mlp.c_fc.weight.shape[1]
+    img = synth.synth_images(3, cfg.image_size, seed=7)
+    with torch.no_grad():
+        pooled, taps = clip.encode_image(img.to(dev), [1, 3])
+    opooled, otaps = O.encode_image(img, sdh, cfg.vision.heads, [1, 3], dtype=torch.float64)
+    assert_close(taps[1], otaps[1], 2e-4, 2e-3, "tap3, fp16-exact weights")
+    assert_close(pooled, opooled, 2e-4, 2e-3, "pooled, fp16-exact weights")
+
+
+@pytest.mark.parametrize("code", [F32, F16X2, F16, BF16])
 def test_tiny_adapted_vs_oracle(dev, code):
     cfg, sd, ia, ta, clip, model = build_tiny(dev, NAME[code])
     img = synth.synth_images(3, cfg.image_size, seed=7)
@@ -288,7 +309,7 @@ def test_tiny_adapted_vs_oracle(dev, code):
     for i in range(2):
         assert_close(seg[i], oseg[i], atol, rtol, f"seg{i}")
     assert_close(det, odet, atol, rtol, "det")
-    assert_close(txt, otxt, 4 * atol if code != F32 else atol, rtol, "adapted text")
+    assert_close(txt, otxt, 4 * atol if code in (F16, BF16) else atol, rtol, "adapted text")
 
 
 def test_lnd_block_api(dev):
