@@ -249,13 +249,16 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 // ratio to the 1e-3 + 1e-2 |ref| bound over taps and maps): all five products 0.14, without Vl.P 0.28, without Kl.Qh
 // 0.82, without Kh.Ql 0.67 -- so Vl.P (20 % of the MFMAs, a quarter of the LDS bytes) is dropped and the other two stay.
 // Stage image: [Kh 8K][Vh 8K][Kl 8K], two stages = 48 KiB: three workgroups per CU.
-template <bool LOG2Q>
-__global__ __launch_bounds__(256, 3) void attn16s_kernel(const f16* __restrict__ qkv, f16* __restrict__ ctx, int L, int H,
+// VL = true keeps the fifth product (stage image + [Vl 8K], two workgroups per CU): short sequences (the text tower's
+// L = 77, the V-V path over the batch axis) have too few keys per row for the averaging argument, and cost nothing.
+template <bool LOG2Q, bool VL>
+__global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __restrict__ qkv, f16* __restrict__ ctx, int L, int H,
                                                          int causal) {
   typedef f16x8 vec8;
   typedef f16x4 vec4;
   typedef short i16x8 __attribute__((ext_vector_type(8)));
-  __shared__ __attribute__((aligned(16))) char smem[49152];   // 2 stages x (Kh 8K + Vh 8K + Kl 8K)
+  constexpr int STAGE = VL ? 32768 : 24576;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];   // 2 stages x (Kh 8K + Vh 8K + Kl 8K [+ Vl 8K])
   constexpr float LOG2E = 1.4426950408889634f;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void attn16s_kernel(const f16* __restrict__
   const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
 
   auto stage = [&](int st, int kt) {
-    char* dst = smem + st * 24576 + wave * 2048;
+    char* dst = smem + st * STAGE + wave * 2048;
     const long step = (long)kt * 64 * ld;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(256, 3) void attn16s_kernel(const f16* __restrict__
       glds16(ksrc[j] + so, dst + j * 1024);
       glds16(vsrc[j] + so, dst + 8192 + j * 1024);
       glds16(ksrc[j] + so + LO, dst + 16384 + j * 1024);
+      if (VL) glds16(vsrc[j] + so + LO, dst + 24576 + j * 1024);
     }
   };
 
@@ -401,10 +405,13 @@ __global__ __launch_bounds__(256, 3) void attn16s_kernel(const f16* __restrict__
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const char* vp = sb + voff[db] + (sub * 32 + 16 * s2) * 128;
-          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp));
-          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + 8 * 128));
-          i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[db] = Elem<f16>::mma32(__builtin_bit_cast(vec8, both), pf, o[db]);
+#pragma unroll
+          for (int part = 0; part < (VL ? 2 : 1); ++part) {   // Vh, then (VL) Vl, 16 KiB further
+            i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + part * 16384));
+            i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + part * 16384 + 8 * 128));
+            i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[db] = Elem<f16>::mma32(__builtin_bit_cast(vec8, both), pf, o[db]);
+          }
         }
       }
   };
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void attn16s_kernel(const f16* __restrict__
     __syncthreads();
     if (kt + 1 >= nkt) break;
     if (kt + 2 < nkt) stage(0, kt + 2);
-    tile(smem + 24576, kt + 1);
+    tile(smem + STAGE, kt + 1);
     wait_vm0();
     __syncthreads();
   }
@@ -1970,8 +1977,13 @@ void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H
                       hipStream_t s) {
   if (dtype == AACLIP_F16X2) {   // split fp16 rows in, split fp16 rows out
     dim3 g((L + 127) / 128, H, B);
-    if (log2q) hipLaunchKernelGGL((attn16s_kernel<true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
-    else hipLaunchKernelGGL((attn16s_kernel<false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    if (L >= 512) {   // long rows: v's lo half is not read (see attn16s_kernel)
+      if (log2q) hipLaunchKernelGGL((attn16s_kernel<true, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16s_kernel<false, false>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    } else {
+      if (log2q) hipLaunchKernelGGL((attn16s_kernel<true, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+      else hipLaunchKernelGGL((attn16s_kernel<false, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal);
+    }
   } else if (dtype == AACLIP_F32 && L >= 64 && g_attn_variant != 1) {   // fp32 MFMA kernel (32 queries per wave)
     dim3 g((L + 127) / 128, H, B);
     hipLaunchKernelGGL(attn32m_kernel, g, dim3(256), 0, s, (const float*)qkv, (float*)ctx, L, H, causal);

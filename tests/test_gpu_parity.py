@@ -49,8 +49,8 @@ def assert_close(a, b, atol, rtol, what=""):
                            f"max err {err.max().item():.3e} at ref {b.flatten()[err.argmax()].item():.3e}")
 
 
-# fp16x2 (fp16 main term + e4m3 correction terms): asserted 5x tighter than the north star on these small models
-TOL = {F32: (2e-4, 1e-3), F16: (1e-3, 1e-2), BF16: (1e-2, 5e-2), F16X2: (2e-4, 2e-3)}
+# fp16x2 (fp16 main term + e4m3 correction terms): asserted 2x tighter than the north star on these small models
+TOL = {F32: (2e-4, 1e-3), F16: (1e-3, 1e-2), BF16: (1e-2, 5e-2), F16X2: (5e-4, 5e-3)}
 
 
 # ----------------------------------------------------------------------------
@@ -287,8 +287,8 @@ def test_tiny_fp16_exact_weights_take_the_three_plane_form(dev):
     with torch.no_grad():
         pooled, taps = clip.encode_image(img.to(dev), [1, 3])
     opooled, otaps = O.encode_image(img, sdh, cfg.vision.heads, [1, 3], dtype=torch.float64)
-    assert_close(taps[1], otaps[1], 2e-4, 2e-3, "tap3, fp16-exact weights")
-    assert_close(pooled, opooled, 2e-4, 2e-3, "pooled, fp16-exact weights")
+    assert_close(taps[1], otaps[1], 5e-4, 5e-3, "tap3, fp16-exact weights")
+    assert_close(pooled, opooled, 5e-4, 5e-3, "pooled, fp16-exact weights")
 
 
 @pytest.mark.parametrize("code", [F32, F16X2, F16, BF16])
@@ -396,7 +396,7 @@ def sampled_close(golden, name, t, atol, rtol):
     assert_close(f[T(golden[f"{name}.idx"])], T(golden[f"{name}.val"]), atol, rtol, name)
 
 
-@pytest.mark.parametrize("code", [F32, F16])
+@pytest.mark.parametrize("code", [F32, F16X2, F16])
 def test_full_model_vs_reference_golden(dev, golden_full, full_weights, code):
     import forward_utils as FU
     model = build_full(dev, NAME[code], full_weights)
@@ -424,11 +424,12 @@ def test_full_model_vs_reference_golden(dev, golden_full, full_weights, code):
         raw = engine.anomaly_map([seg[i]], ganch, 37, 1, 1.0)   # S == grid: identity upsample
         # measured on MI355X (tests/test_gpu_configs.py docstring, profiles/r02_parity_errors.json): fp32 path max
         # |err| ~1e-5; fp16 path <= 2.9e-3 per level -- the fp16 tower's rounding noise x50, not the head
-        assert_close(raw, T(golden_full[f"full.map_pre_blur{i}"]), 4e-3 if code != F32 else 1e-4,
-                     rtol if code != F32 else 1e-3, f"pre-blur map {i}")
+        # fp16x2: the north star itself (B = 2: the small-batch kernels; the large-batch ones: test_gpu_configs.py)
+        matol = {F32: 1e-4, F16X2: 1e-3}.get(code, 4e-3)
+        assert_close(raw, T(golden_full[f"full.map_pre_blur{i}"]), matol, rtol if code != F32 else 1e-3, f"pre-blur map {i}")
     tfb = ganch.unsqueeze(0).repeat(2, 1, 1)
     sampled_close(golden_full, "full.map_train3", FU.calculate_similarity_map(seg[3], tfb, 518, test=False),
-                  2e-3 if code != F32 else 2e-4, rtol)
+                  {F32: 2e-4, F16X2: 5e-4}.get(code, 2e-3), rtol)
 
 
 def test_full_encode_image_vs_reference_golden(dev, golden_full, full_weights):

@@ -189,7 +189,7 @@ def test_attention_split(dev, cfg, log2q):
     """q.k^T on 3 products (q and k with their lo halves), p.v on one (p and v in fp16: v's lo half is read by nobody,
     see attention.hip).  Against fp64 attention of the same q, k and the fp16-rounded v the context is within ~3e-4
     -- the fp16 rounding of p averaged over the row -- where plain fp16 is asserted at 3e-3; the rounding of v itself
-    is a property of the format, bounded separately below."""
+    is a property of the format, bounded separately below.  Rows shorter than 512 keys use v's lo half as well."""
     lib = _lib.load()
     B, L, H, causal = cfg
     D = H * 64
@@ -203,7 +203,8 @@ def test_attention_split(dev, cfg, log2q):
     if log2q:
         f[:, :D] *= 0.6931471805599453
     exact = _attn_ref(f, B, L, H, causal)
-    f[:, 2 * D:] = f[:, 2 * D:].half().float()
+    if L >= 512:      # long rows: v in fp16 (short ones keep v's lo half)
+        f[:, 2 * D:] = f[:, 2 * D:].half().float()
     ref = _attn_ref(f, B, L, H, causal)
     assert_close(join8(ctx, D), ref, 4e-4, 1e-3, f"attention split {cfg}")
     # v in fp16: a row of the context moves by at most 2^-11 of the largest |v| it averages
@@ -235,7 +236,8 @@ def test_attention_first_tile_far_below_zero(dev, code, L, causal):
         ref_in = qkv.clone()
     _lib.check(lib.aaclip_attention_log2q(code, qd.data_ptr(), ctx.data_ptr(), 1, L, H, causal, stream(dev)))
     ref_in[:, :64] *= 0.6931471805599453
-    ref_in[:, 128:] = ref_in[:, 128:].half().float()
+    if L >= 512:
+        ref_in[:, 128:] = ref_in[:, 128:].half().float()
     ref = _attn_ref(ref_in, 1, L, H, causal)
     got = ctx.float() if code == F16 else join8(ctx, D)
     assert_close(got, ref, 3e-3 if code == F16 else 4e-4, 1e-2, f"first tile -150, L={L}, causal={causal}")
