@@ -368,7 +368,7 @@ def run_rank(args):
                     "peak": peak,
                     "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4),
-                    **traffic_fields(args.precision, B),
+                    **traffic_fields(args.precision, B, args.clip_weights),
                     "launches_timed": len(fc_ms),
                     "avg_launch_ms": round(fc_avg, 4),
                     "flop_per_launch": fc_flop,
@@ -447,7 +447,7 @@ def companion(precision, build, args, B, dev, torch):
             "peak_tflops": PEAK_TFLOPS[precision], "parity_vs_north_star": parity_fields(precision)}
 
 
-def traffic_fields(precision, batch):
+def traffic_fields(precision, batch, clip_weights="fp32"):
     """`traffic` = HBM bytes per launch of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), measured offline
     on this kernel and shape and committed under profiles/.  A committed measurement only counts for the kernel it was
@@ -464,7 +464,8 @@ def traffic_fields(precision, batch):
                 t = json.load(f)
         except (OSError, ValueError):
             continue
-        if precision != "fp16" or t.get("shape") != [batch * 1370, 4096, 1024]:
+        if (t.get("precision", "fp16") != precision or t.get("shape") != [batch * 1370, 4096, 1024]
+                or (precision == "fp16x2" and t.get("clip_weights", "fp32") != clip_weights)):
             continue
         rel = os.path.relpath(path, REPO)
         if t.get("kernel_revision") != rev:

@@ -110,18 +110,28 @@ def main():
         pmcjson(sys.argv[2], sys.argv[3], sys.argv[4:])
     elif mode == "traffic":
         fetch_db, write_db, sub, M, N, K, out = sys.argv[2:9]
+        precision = sys.argv[9] if len(sys.argv) > 9 else "fp16"
+        clip_weights = sys.argv[10] if len(sys.argv) > 10 else "fp32"
         M, N, K = int(M), int(N), int(K)
+        # operand bytes of the arithmetic mode: fp16 = 2 per element; fp16x2 = split rows, 4 per element (3 for the A
+        # and W planes that are actually read when the weight is exact in fp16: the hi8 / Wl8 planes are not touched)
+        if precision == "fp16x2":
+            ab = 3 if clip_weights == "fp16" else 4
+            algo = M * K * ab + N * K * ab + M * N * 4
+        else:
+            algo = M * K * 2 + N * K * 2 + M * N * 2
         f = counter_values(fetch_db, sub)["FETCH_SIZE"]
         w = counter_values(write_db, sub)["WRITE_SIZE"]
         f_kb, w_kb = sum(f) / len(f), sum(w) / len(w)
         from aaclip_hip._lib import kernel_source_revision
         doc = {
-            "kernel": sub, "shape": [M, N, K], "launches": [len(f), len(w)],
+            "kernel": sub, "shape": [M, N, K], "launches": [len(f), len(w)], "precision": precision,
+            "clip_weights": clip_weights,
             "kernel_revision": kernel_source_revision(),   # bench.py refuses this file once the kernel sources change
             "FETCH_SIZE_raw_kb": f_kb, "WRITE_SIZE_raw_kb": w_kb,
             "fetch_bytes_corrected_x2": f_kb * 1024 * 2, "write_bytes": w_kb * 1024,
             "traffic_bytes_per_launch": f_kb * 1024 * 2 + w_kb * 1024,
-            "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * N * 2,
+            "algorithmic_bytes_per_launch": algo,
             "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per "
                     "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
         }
