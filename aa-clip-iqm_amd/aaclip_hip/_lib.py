@@ -62,6 +62,10 @@ SIGNATURES = {
     "aaclip_attention_log2q": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aaclip_adapter_mix": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "aaclip_small_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "aaclip_cross_rows_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "aaclip_cross_rows": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "aaclip_head_expand": (_i, [_i, _vp, _vp, _l, _i, _i, _f, _vp]),
+    "aaclip_head_diag": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "aaclip_residual_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "aaclip_combine3": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _l, _vp]),
     "aaclip_linear_smallk": (_i, [_i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),

@@ -607,6 +607,38 @@ def small_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, n
     return out
 
 
+def cross_rows(qt: torch.Tensor, x: torch.Tensor, B: int, R: int, Lk: int, x_code: int) -> torch.Tensor:
+    """out[b, r] = softmax_j(qt[b, r] . x[b, j]) . x[b]: R effective queries per image over the raw rows x [B*Lk, Dk]
+    (reference model/iqm.py:108-139 after folding W_k into the query and W_v behind the weighted sum; include/aaclip.h).
+    qt fp32 [B*R, Dk] -> fp32 [B*R, Dk]."""
+    lib = _lib.load()
+    Dk = x.shape[-1]
+    out = torch.empty(B * R, Dk, dtype=torch.float32, device=x.device)
+    ws = Workspace.get(x.device, lib.aaclip_cross_rows_workspace_bytes(B, R, Lk, Dk) + 256)
+    _lib.check(lib.aaclip_cross_rows(x_code, qt.data_ptr(), x.data_ptr(), out.data_ptr(), B, R, Lk, Dk, ws.data_ptr(),
+                                     ws.numel(), _stream(x.device)), "cross_rows")
+    return out
+
+
+def head_expand(q: torch.Tensor, heads: int, scale: float, code: int) -> torch.Tensor:
+    """q fp32 [rows, D] -> [rows*H, D] in the compute dtype: row (r, h) = q[r] * scale on head h's columns, else zero."""
+    rows, D = q.shape
+    out = torch.empty(rows * heads, D, dtype=_TORCH_DT[code], device=q.device)
+    _lib.check(_lib.load().aaclip_head_expand(code, q.data_ptr(), out.data_ptr(), rows, heads, D, float(scale),
+                                              _stream(q.device)), "head_expand")
+    return out
+
+
+def head_diag(full: torch.Tensor, heads: int) -> torch.Tensor:
+    """full fp32 [rows*H, D] -> [rows, D]: the head-diagonal blocks (row (r, h), columns of head h)."""
+    D = full.shape[-1]
+    rows = full.shape[0] // heads
+    out = torch.empty(rows, D, dtype=torch.float32, device=full.device)
+    _lib.check(_lib.load().aaclip_head_diag(full.data_ptr(), out.data_ptr(), rows, heads, D, _stream(full.device)),
+               "head_diag")
+    return out
+
+
 def residual_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], ln, eps: float) -> torch.Tensor:
     """LayerNorm(a + b) (reference model/iqm.py:150-154); fp32 [rows, D]."""
     rows, D = a.shape

@@ -244,6 +244,34 @@ int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const vo
   return finish("small_attention");
 }
 
+size_t aaclip_cross_rows_workspace_bytes(int B, int R, int Lk, int Dk) { return cross_rows_ws_bytes(B, R, Lk, Dk); }
+
+int aaclip_cross_rows(int x_dtype, const float* qt, const void* x, float* out, int B, int R, int Lk, int Dk, void* ws,
+                      size_t ws_bytes, void* stream) {
+  REQUIRE(plain_dtype_ok(x_dtype), "cross_rows: bad dtype (fp32, fp16 or bf16)");
+  REQUIRE(qt && x && out && ws, "cross_rows: null pointer");
+  REQUIRE(B > 0 && B <= 65535, "cross_rows: bad batch");
+  const char* m = cross_rows_check(R, Lk, Dk);
+  if (m) return fail(-1, m);
+  REQUIRE(ws_bytes >= cross_rows_ws_bytes(B, R, Lk, Dk), "cross_rows: workspace too small");
+  launch_cross_rows(x_dtype, qt, x, out, ws, B, R, Lk, Dk, (hipStream_t)stream);
+  return finish("cross_rows");
+}
+
+int aaclip_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, void* stream) {
+  REQUIRE(plain_dtype_ok(dtype), "head_expand: bad dtype (fp32, fp16 or bf16)");
+  REQUIRE(q && qm && rows > 0 && H > 0 && D > 0 && D % H == 0, "head_expand: bad arguments");
+  REQUIRE(rows * H < (1L << 31), "head_expand: too many rows");
+  launch_head_expand(dtype, q, qm, rows, H, D, scale, (hipStream_t)stream);
+  return finish("head_expand");
+}
+
+int aaclip_head_diag(const float* full, float* ctx, long rows, int H, int D, void* stream) {
+  REQUIRE(full && ctx && rows > 0 && rows < (1L << 31) && H > 0 && D > 0 && D % H == 0, "head_diag: bad arguments");
+  launch_head_diag(full, ctx, rows, H, D, (hipStream_t)stream);
+  return finish("head_diag");
+}
+
 int aaclip_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,
                               int D, float eps, void* stream) {
   REQUIRE(a && w && bias && out, "residual_layernorm: null pointer");

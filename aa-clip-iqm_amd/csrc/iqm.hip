@@ -148,6 +148,160 @@ __global__ __launch_bounds__(256) void small_attention_kernel(const float* __res
   }
 }
 
+// ---- cross_rows: attention of a handful of EFFECTIVE queries over raw (unprojected) rows.
+// IQM's cross-attention projects 4 x 1369 patch rows per image through W_k and W_v (2 x 5476 x 768 x 768 MACs per
+// layer and image) to be consumed by two queries.  The algebra avoids both products:
+//   scores_j = q_h . (W_k[h] x_j + b_k[h]) / sqrt(d) = (W_k[h]^T q_h / sqrt(d)) . x_j + const   (const: softmax-invariant)
+//   ctx_h    = sum_j p_j (W_v[h] x_j + b_v[h])       = W_v[h] (sum_j p_j x_j) + b_v[h]
+// so per (image, query, head) one effective query qt = W_k[h]^T q_h / sqrt(d) in the rows' own space (a [R, Dk] GEMM on
+// the 2-row query side), this kernel for ebar = softmax(qt X^T) X over the raw rows X [Lk, Dk], and one more small GEMM
+// for W_v[h] ebar + b_v[h].  R = queries x heads rows of qt per image (16 for IQM), all attending to the same X.
+//   partial: grid (slices, B), R / 4 waves; a wave owns 4 rows of qt and walks the slice's keys: the key row is read
+//            once per wave (coalesced, 4 elements per lane and 256-column chunk), 4 dot products by wave reduction,
+//            online softmax per query row (running maximum, sum, accumulator [4][Dk / 64] per lane)
+//   combine: merges the slices' (m, l, acc) in a fixed order (deterministic)
+constexpr int CR_SLICES = 8;
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void cross_rows_partial_kernel(const float* __restrict__ qt, const T* __restrict__ x,
+                                                                 float* __restrict__ part, int R, int Lk, int slices) {
+  constexpr int Dk = NCH * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sl = blockIdx.x, b = blockIdx.y;
+  const int r0 = wave * 4;
+  if (r0 >= R) return;
+  const int per = (Lk + slices - 1) / slices;
+  const int j0 = sl * per, j1 = min(Lk, j0 + per);
+  f32x4 q[4][NCH], acc[4][NCH];
+  float m[4], l[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    m[a] = -INFINITY;
+    l[a] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      q[a][c] = *(const f32x4*)(qt + ((long)b * R + r0 + a) * Dk + (c * 64 + lane) * 4);
+      acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  for (int j = j0; j < j1; ++j) {
+    const T* xr = x + ((long)b * Lk + j) * Dk;
+    f32x4 xv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (sizeof(T) == 4) {
+        xv[c] = *(const f32x4*)((const float*)xr + (c * 64 + lane) * 4);
+      } else {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const t4 v = *(const t4*)(xr + (c * 64 + lane) * 4);
+        xv[c] = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+      }
+    }
+    float s[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        d = fmaf(xv[c][3], q[a][c][3], fmaf(xv[c][2], q[a][c][2], fmaf(xv[c][1], q[a][c][1], fmaf(xv[c][0], q[a][c][0], d))));
+      s[a] = wave_sum(d);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (s[a] > m[a]) {            // wave-uniform: every lane holds the same score
+        const float f = expf(m[a] - s[a]);   // exp(-inf) = 0 on the first key
+        l[a] *= f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[a][c] = acc[a][c] * f;
+        m[a] = s[a];
+      }
+      const float pj = expf(s[a] - m[a]);
+      l[a] += pj;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[a][c] = acc[a][c] + xv[c] * pj;
+    }
+  }
+  // partial record of (b, slice, row): [Dk accumulator][m][l]
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float* pr = part + (((long)b * slices + sl) * R + r0 + a) * (Dk + 2);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *(f32x4*)(pr + (c * 64 + lane) * 4) = acc[a][c];
+    if (lane == 0) { pr[Dk] = m[a]; pr[Dk + 1] = l[a]; }
+  }
+}
+__global__ __launch_bounds__(256) void cross_rows_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                 int R, int Dk, int slices) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  float m = -INFINITY;
+  for (int s = 0; s < slices; ++s) m = fmaxf(m, part[(((long)b * slices + s) * R + r) * (Dk + 2) + Dk]);
+  float l = 0.f;
+  for (int s = 0; s < slices; ++s) {
+    const float* pr = part + (((long)b * slices + s) * R + r) * (Dk + 2);
+    if (pr[Dk + 1] > 0.f) l += pr[Dk + 1] * expf(pr[Dk] - m);
+  }
+  const float inv = 1.0f / l;
+  for (int d = threadIdx.x; d < Dk; d += 256) {
+    float a = 0.f;
+    for (int s = 0; s < slices; ++s) {
+      const float* pr = part + (((long)b * slices + s) * R + r) * (Dk + 2);
+      if (pr[Dk + 1] > 0.f) a += pr[d] * expf(pr[Dk] - m);
+    }
+    out[((long)b * R + r) * Dk + d] = a * inv;
+  }
+}
+const char* cross_rows_check(int R, int Lk, int Dk) {
+  if (R < 4 || R > 16 || (R & 3)) return "cross_rows: 4, 8, 12 or 16 effective queries per image";
+  if (Lk < 1) return "cross_rows: no keys";
+  if (Dk != 256 && Dk != 512 && Dk != 768 && Dk != 1024) return "cross_rows: row width must be 256, 512, 768 or 1024";
+  return nullptr;
+}
+int cross_rows_slices(int Lk) { return Lk >= 64 * CR_SLICES ? CR_SLICES : (Lk >= 64 ? Lk / 64 : 1); }
+size_t cross_rows_ws_bytes(int B, int R, int Lk, int Dk) { return (size_t)B * cross_rows_slices(Lk) * R * (Dk + 2) * 4; }
+template <typename T>
+static void cross_rows_t(const float* qt, const T* x, float* out, float* part, int B, int R, int Lk, int Dk, hipStream_t s) {
+  const int slices = cross_rows_slices(Lk);
+  dim3 g(slices, B), blk(64 * (R / 4));
+  switch (Dk / 256) {
+    case 1: hipLaunchKernelGGL((cross_rows_partial_kernel<T, 1>), g, blk, 0, s, qt, x, part, R, Lk, slices); break;
+    case 2: hipLaunchKernelGGL((cross_rows_partial_kernel<T, 2>), g, blk, 0, s, qt, x, part, R, Lk, slices); break;
+    case 3: hipLaunchKernelGGL((cross_rows_partial_kernel<T, 3>), g, blk, 0, s, qt, x, part, R, Lk, slices); break;
+    case 4: hipLaunchKernelGGL((cross_rows_partial_kernel<T, 4>), g, blk, 0, s, qt, x, part, R, Lk, slices); break;
+  }
+  hipLaunchKernelGGL(cross_rows_combine_kernel, dim3(R, B), dim3(256), 0, s, part, out, R, Dk, slices);
+}
+void launch_cross_rows(int x_dtype, const float* qt, const void* x, float* out, void* ws, int B, int R, int Lk, int Dk,
+                       hipStream_t s) {
+  if (x_dtype == AACLIP_F32) cross_rows_t<float>(qt, (const float*)x, out, (float*)ws, B, R, Lk, Dk, s);
+  else if (x_dtype == AACLIP_F16) cross_rows_t<f16>(qt, (const f16*)x, out, (float*)ws, B, R, Lk, Dk, s);
+  else cross_rows_t<bf16>(qt, (const bf16*)x, out, (float*)ws, B, R, Lk, Dk, s);
+}
+
+// head_expand: q [rows, D] fp32 -> qm [rows * H, D] of T, row (r, h) = q[r] * scale inside head h's column slice, zero
+// outside -- the A operand of the effective-query product qt = qm . W_k (all heads in one GEMM).
+template <typename T>
+__global__ __launch_bounds__(256) void head_expand_kernel(const float* __restrict__ q, T* __restrict__ qm, int H, int D,
+                                                          float scale) {
+  const long r = blockIdx.x / H;
+  const int h = blockIdx.x % H, hd = D / H;
+  for (int d = threadIdx.x; d < D; d += 256)
+    qm[(long)blockIdx.x * D + d] = from_float<T>((d / hd == h) ? q[r * D + d] * scale : 0.f);
+}
+void launch_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, hipStream_t s) {
+  dim3 g((unsigned)(rows * H));
+  if (dtype == AACLIP_F32) hipLaunchKernelGGL(head_expand_kernel<float>, g, dim3(256), 0, s, q, (float*)qm, H, D, scale);
+  else if (dtype == AACLIP_F16) hipLaunchKernelGGL(head_expand_kernel<f16>, g, dim3(256), 0, s, q, (f16*)qm, H, D, scale);
+  else hipLaunchKernelGGL(head_expand_kernel<bf16>, g, dim3(256), 0, s, q, (bf16*)qm, H, D, scale);
+}
+// head_diag: full [rows * H, D] fp32 -> ctx [rows, D]: ctx[r, h*hd + d] = full[(r, h), h*hd + d]
+__global__ __launch_bounds__(256) void head_diag_kernel(const float* __restrict__ full, float* __restrict__ ctx, int H, int D) {
+  const long r = blockIdx.x;
+  const int hd = D / H;
+  for (int d = threadIdx.x; d < D; d += 256) ctx[r * D + d] = full[(r * H + d / hd) * D + d];
+}
+void launch_head_diag(const float* full, float* ctx, long rows, int H, int D, hipStream_t s) {
+  hipLaunchKernelGGL(head_diag_kernel, dim3((unsigned)rows), dim3(256), 0, s, full, ctx, H, D);
+}
+
 const char* small_attention_check(int nq, int Lk, int H, int hd) {
   if (nq < 1 || nq > SA_MAXQ) return "small_attention: 1..4 queries per image";
   if (Lk < 1 || Lk > SA_MAXK) return "small_attention: 1..8192 keys";

@@ -105,6 +105,12 @@ void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int 
 const char* small_attention_check(int nq, int Lk, int H, int hd);
 void launch_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
                             int H, int hd, float scale, hipStream_t s);
+const char* cross_rows_check(int R, int Lk, int Dk);
+size_t cross_rows_ws_bytes(int B, int R, int Lk, int Dk);
+void launch_cross_rows(int x_dtype, const float* qt, const void* x, float* out, void* ws, int B, int R, int Lk, int Dk,
+                       hipStream_t s);
+void launch_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, hipStream_t s);
+void launch_head_diag(const float* full, float* ctx, long rows, int H, int D, hipStream_t s);
 void launch_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,
                                int D, float eps, hipStream_t s);
 void launch_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, long n,

@@ -111,6 +111,24 @@ class IQM(nn.Module):
         q = torch.empty(B * nq, D, dtype=torch.float32, device=h.device)
         engine.gemm(code, EPI_ACT_F32, hq, engine.CACHE.get(att.attention.query.weight, code),
                     engine._f32c(att.attention.query.bias), q)
+        H = self.num_attention_heads
+        if enc is not None and (nq * H) % 4 == 0 and nq * H <= 16 and enc.shape[-1] in (256, 512, 768, 1024):
+            # cross-attention over MANY rows for a handful of queries: W_k moves to the query side and W_v behind the
+            # probability-weighted sum of the raw rows (include/aaclip.h, aaclip_cross_rows): the reference's key /
+            # value projections of all Lk rows (2 x Lk x Dk x D MACs per image, reference model/iqm.py:116-121) become
+            # two [nq*H, .] products.  b_k only shifts every score of a row by the same amount: softmax-invariant.
+            qm = engine.head_expand(q, H, 1.0 / math.sqrt(D // H), code)                         # [B*nq*H, D]
+            qt = torch.empty(B * nq * H, enc.shape[-1], dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, qm, engine.CACHE.get(att.attention.key.weight, code, "transpose"), None, qt)
+            ebar = engine.cross_rows(qt, enc, B, nq * H, Lk, code)                               # [B*nq*H, Dk] fp32
+            full = torch.empty(B * nq * H, D, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, ebar.to(dt), engine.CACHE.get(att.attention.value.weight, code),
+                        engine._f32c(att.attention.value.bias), full)
+            ctx = engine.head_diag(full, H)
+            dense = torch.empty(B * nq, D, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, ctx.to(dt), engine.CACHE.get(att.output.dense.weight, code),
+                        engine._f32c(att.output.dense.bias), dense)
+            return engine.residual_layernorm(dense, h, att.output.LayerNorm, self.eps)
         src = hq if enc is None else enc
         k = torch.empty(src.shape[0], D, dtype=dt, device=h.device)      # compute dtype (fp32 on the fp32 path)
         v = torch.empty_like(k)

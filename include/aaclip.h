@@ -264,6 +264,20 @@ int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight,
 /* softmax(q k^T * scale) v per (image, head) for nq <= 4 queries over Lk <= 8192 keys: the core of
  * IQM_MultiHeadAttention.forward (reference model/iqm.py:108-139; masks are all-zero on this path, dropout is the
  * identity in eval).  q, out [B, nq, H*hd] fp32; k, v [B*Lk, H*hd] in kv_dtype; hd a multiple of 4, <= 128. */
+/* Cross-attention of IQM without the key / value projections of the patch rows (reference model/iqm.py:108-139 with
+ * encoder_hidden_states = the 4 x 1369 projected patch rows; the reference projects every row through W_k and W_v):
+ *   scores_j = q_h . (W_k[h] x_j + b_k[h]) / sqrt(d) = (W_k[h]^T q_h / sqrt(d)) . x_j + const  (softmax-invariant)
+ *   ctx_h    = sum_j p_j (W_v[h] x_j + b_v[h])       = W_v[h] (sum_j p_j x_j) + b_v[h]
+ * aaclip_head_expand builds the A operand of the effective-query product (q [rows, D] fp32 -> [rows * H, D] dtype, row
+ * (r, h) = q[r] * scale on head h's columns, zero elsewhere; qt = that . W_k through aaclip_gemm);
+ * aaclip_cross_rows computes out[b, r] = softmax_j(qt[b, r] . x[b, j]) . x[b] for R = queries x heads effective
+ * queries per image over the raw rows x [B * Lk, Dk] (x_dtype), fp32 accumulation, qt / out [B, R, Dk] fp32;
+ * aaclip_head_diag picks the head-diagonal blocks of the [rows * H, D] product W_v . ebar + b_v -> ctx [rows, D]. */
+size_t aaclip_cross_rows_workspace_bytes(int B, int R, int Lk, int Dk);
+int aaclip_cross_rows(int x_dtype, const float* qt, const void* x, float* out, int B, int R, int Lk, int Dk, void* ws,
+                      size_t ws_bytes, void* stream);
+int aaclip_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, void* stream);
+int aaclip_head_diag(const float* full, float* ctx, long rows, int H, int D, void* stream);
 int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
                            int H, int hd, float scale, void* stream);
 /* out = LayerNorm(a + b) over the last dimension D (b may be NULL): IQM_SelfOutput / IQM_Output (reference

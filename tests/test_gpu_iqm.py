@@ -58,6 +58,44 @@ def test_small_attention(dev, kv, shape):
     close(out, ref, 2e-5, 1e-5, f"small_attention {shape}")      # k, v are exact inputs in every dtype
 
 
+@pytest.mark.parametrize("code", [F32, F16, BF16])
+@pytest.mark.parametrize("shape", [(3, 2, 8, 5476, 768), (2, 2, 8, 768, 768), (1, 1, 4, 50, 256), (2, 4, 4, 700, 512)])
+def test_cross_rows_equals_projected_cross_attention(dev, code, shape):
+    """The algebra of include/aaclip.h (aaclip_cross_rows): W_k folded into the query, W_v applied after the
+    probability-weighted sum of the RAW rows -- against the reference's order of operations (project every row
+    through W_k and W_v, then attend per head; reference model/iqm.py:108-139) in fp64 on the same inputs."""
+    B, nq, H, Lk, D = shape
+    hd = D // H
+    q = synth.randn("cr.q", (B * nq, D), 1.0, 1)
+    x = synth.randn("cr.x", (B * Lk, D), 1.0, 2).to(TDT[code])
+    Wk, Wv = synth.randn("cr.wk", (D, D), D ** -0.5, 3), synth.randn("cr.wv", (D, D), D ** -0.5, 4)
+    bk, bv = synth.randn("cr.bk", (D,), 0.3, 5), synth.randn("cr.bv", (D,), 0.3, 6)
+    # reference order, fp64
+    xd = x.double()
+    k = (xd @ Wk.double().t() + bk.double()).view(B, Lk, H, hd).transpose(1, 2)
+    v = (xd @ Wv.double().t() + bv.double()).view(B, Lk, H, hd).transpose(1, 2)
+    qh = q.double().view(B, nq, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qh @ k.transpose(-1, -2) / hd ** 0.5, -1) @ v).transpose(1, 2).reshape(B * nq, D)
+    # the build's order: effective queries, attention over the raw rows, value projection of the weighted sums (fp32
+    # products through torch here: the GEMMs themselves are tested elsewhere)
+    qm = engine.head_expand(q.to(dev), H, 1.0 / hd ** 0.5, F32)
+    assert qm.shape == (B * nq * H, D)
+    want = torch.zeros(B * nq, H, D)
+    for h in range(H):
+        want[:, h, h * hd:(h + 1) * hd] = q[:, h * hd:(h + 1) * hd] / hd ** 0.5
+    assert torch.allclose(qm.cpu(), want.view(-1, D), atol=1e-7)
+    qt = (qm.double().cpu() @ Wk.double()).float().to(dev)                    # [B*nq*H, D]: W_k[h]^T q_h
+    ebar = engine.cross_rows(qt, x.to(dev), B, nq * H, Lk, code)
+    p = torch.softmax(qt.double().cpu().view(B, nq * H, D) @ xd.view(B, Lk, D).transpose(1, 2), -1)
+    close(ebar, (p @ xd.view(B, Lk, D)).view(-1, D), 2e-5, 1e-5, f"cross_rows {shape}")
+    full = (ebar.double().cpu() @ Wv.double().t() + bv.double()).float().to(dev)
+    ctx = engine.head_diag(full, H)
+    close(ctx, ref, 5e-5, 2e-5, f"algebraic vs projected order {shape}")
+    lib = _lib.load()
+    assert lib.aaclip_cross_rows(code, 1, 1, 1, 2, 6, 100, 768, 1, 1 << 30, None) < 0          # R = 6: refused
+    assert lib.aaclip_cross_rows(code, 1, 1, 1, 2, 16, 100, 768, 1, 16, None) < 0              # workspace too small
+
+
 def test_residual_layernorm_combine_smallk_dropcls(dev):
     lib = _lib.load()
     a, b = synth.randn("iq.a", (10, 768), 2.0, 1, 0.5), synth.randn("iq.b", (10, 768), 1.0, 2)
