@@ -160,7 +160,20 @@ __global__ __launch_bounds__(256) void small_attention_kernel(const float* __res
 //            once per wave (coalesced, 4 elements per lane and 256-column chunk), 4 dot products by wave reduction,
 //            online softmax per query row (running maximum, sum, accumulator [4][Dk / 64] per lane)
 //   combine: merges the slices' (m, l, acc) in a fixed order (deterministic)
-constexpr int CR_SLICES = 8;
+constexpr int CR_SLICES = 16;
+// Sum over the 64 lanes on the VALU's DPP paths (rotations inside the rows of 16, then row_bcast:15 / row_bcast:31),
+// result broadcast from lane 63 through an SGPR: 6 adds + 1 v_readlane instead of 6 LDS-crossbar shuffles.  The order
+// of the additions is fixed, so results do not depend on anything but the inputs.
+AACLIP_DEV float wave_sum_dpp(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+  // every lane of a row of 16 now holds its row's sum; add row 0 into row 1 and row 2 into row 3, then rows 0+1 into 3
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void cross_rows_partial_kernel(const float* __restrict__ qt, const T* __restrict__ x,
                                                                  float* __restrict__ part, int R, int Lk, int slices) {
@@ -183,9 +196,12 @@ __global__ __launch_bounds__(256) void cross_rows_partial_kernel(const float* __
       acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
-  for (int j = j0; j < j1; ++j) {
-    const T* xr = x + ((long)b * Lk + j) * Dk;
-    f32x4 xv[NCH];
+  // keys in groups of KB: all loads of a group are issued before any arithmetic (a wave walks its keys one after the
+  // other; with one key in flight the loop ran at the memory latency: 0.8 ms per call for 5476 keys)
+  constexpr int KB = 4;
+  auto load_key = [&](int j, f32x4 (&xv)[NCH]) {
+    const int jj = j < j1 ? j : j1 - 1;          // the tail group re-reads the last key (its result is skipped)
+    const T* xr = x + ((long)b * Lk + jj) * Dk;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (sizeof(T) == 4) {
@@ -196,28 +212,38 @@ __global__ __launch_bounds__(256) void cross_rows_partial_kernel(const float* __
         xv[c] = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
       }
     }
-    float s[4];
+  };
+  for (int j = j0; j < j1; j += KB) {
+    f32x4 xk[KB][NCH];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      float d = 0.f;
+    for (int u = 0; u < KB; ++u) load_key(j + u, xk[u]);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        d = fmaf(xv[c][3], q[a][c][3], fmaf(xv[c][2], q[a][c][2], fmaf(xv[c][1], q[a][c][1], fmaf(xv[c][0], q[a][c][0], d))));
-      s[a] = wave_sum(d);
-    }
+    for (int u = 0; u < KB; ++u) {
+      if (j + u >= j1) break;
+      const f32x4 (&xv)[NCH] = xk[u];
+      float s[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (s[a] > m[a]) {            // wave-uniform: every lane holds the same score
-        const float f = expf(m[a] - s[a]);   // exp(-inf) = 0 on the first key
-        l[a] *= f;
+      for (int a = 0; a < 4; ++a) {
+        float d = 0.f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) acc[a][c] = acc[a][c] * f;
-        m[a] = s[a];
+        for (int c = 0; c < NCH; ++c)
+          d = fmaf(xv[c][3], q[a][c][3], fmaf(xv[c][2], q[a][c][2], fmaf(xv[c][1], q[a][c][1], fmaf(xv[c][0], q[a][c][0], d))));
+        s[a] = wave_sum_dpp(d) * 1.4426950408889634f;   // log2 units: one v_exp_f32 per probability
       }
-      const float pj = expf(s[a] - m[a]);
-      l[a] += pj;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[a][c] = acc[a][c] + xv[c] * pj;
+      for (int a = 0; a < 4; ++a) {
+        if (s[a] > m[a]) {            // wave-uniform: every lane holds the same score
+          const float f = __builtin_amdgcn_exp2f(m[a] - s[a]);   // 2^-inf = 0 on the first key
+          l[a] *= f;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[a][c] = acc[a][c] * f;
+          m[a] = s[a];
+        }
+        const float pj = __builtin_amdgcn_exp2f(s[a] - m[a]);
+        l[a] += pj;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[a][c] = acc[a][c] + xv[c] * pj;
+      }
     }
   }
   // partial record of (b, slice, row): [Dk accumulator][m][l]
@@ -237,14 +263,14 @@ __global__ __launch_bounds__(256) void cross_rows_combine_kernel(const float* __
   float l = 0.f;
   for (int s = 0; s < slices; ++s) {
     const float* pr = part + (((long)b * slices + s) * R + r) * (Dk + 2);
-    if (pr[Dk + 1] > 0.f) l += pr[Dk + 1] * expf(pr[Dk] - m);
+    if (pr[Dk + 1] > 0.f) l += pr[Dk + 1] * exp2f(pr[Dk] - m);   // the partial maxima are in log2 units
   }
   const float inv = 1.0f / l;
   for (int d = threadIdx.x; d < Dk; d += 256) {
     float a = 0.f;
     for (int s = 0; s < slices; ++s) {
       const float* pr = part + (((long)b * slices + s) * R + r) * (Dk + 2);
-      if (pr[Dk + 1] > 0.f) a += pr[d] * expf(pr[Dk] - m);
+      if (pr[Dk + 1] > 0.f) a += pr[d] * exp2f(pr[Dk] - m);
     }
     out[((long)b * R + r) * Dk + d] = a * inv;
   }

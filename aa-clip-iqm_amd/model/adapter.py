@@ -162,15 +162,15 @@ class AdaptedCLIP(nn.Module):
         engine.gemm(code, EPI_ACT_F32, t1.to(dt), engine.CACHE.get(m2.weight, code), engine._f32c(m2.bias), cq)
         pos = engine._f32c(self.pos_embedding)[:, :2, :].expand(B, 2, h).contiguous()
         query = engine.combine3(cq.unsqueeze(1).expand(B, 2, h).contiguous(), pos, None, 1.0, 1.0, 0.0)
-        # 2. patch rows of all levels -> query space (:210-221)
+        # 2. patch rows of all levels -> query space (:210-221): visual_feature_proj is NOT applied to the 5476 rows per
+        #    image; it is folded into the two cross-attentions that read them (IQM._attend, enc_proj)
         vp = self.visual_feature_proj
-        vis = torch.empty(vis_cat.shape[0] * vis_cat.shape[1], h, dtype=dt, device=dev)
-        engine.gemm(code, EPI_BIAS, vis_cat.view(-1, h), engine.CACHE.get(vp.weight, code), engine._f32c(vp.bias), vis)
         # 3. anchors [B, 768, 2] read as 768 tokens of width 2 -> Linear(2, 768) (:229-246)
         tp = self.text_feature_proj
         txt = engine.linear_smallk(te, tp.weight, tp.bias, code)
-        out = self.iqm(query_embeds=query, query_length=2, encoder_hidden_states=vis.view(B, -1, h),
-                       text_encoder_hidden_states=txt.view(B, te.shape[1], tp.weight.shape[0]), code=code)
+        out = self.iqm(query_embeds=query, query_length=2, encoder_hidden_states=vis_cat,
+                       text_encoder_hidden_states=txt.view(B, te.shape[1], tp.weight.shape[0]), code=code,
+                       encoder_proj=(vp.weight, vp.bias))
         hfin = engine.residual_layernorm(out.last_hidden_state.reshape(B * 2, h), None, self.iqm_layer_norm,
                                          self.iqm_layer_norm.eps)                             # :265-266
         return IQMOutput(hfin.view(B, 2, h), pooler_output=out.last_hidden_state.reshape(B, 2, h)[:, 0, :])

@@ -104,7 +104,7 @@ class IQM(nn.Module):
 
     # ---- one IQM_Attention: q from h [B*nq, D] (fp32), k/v = Linear(enc) where enc is [B*Lk, Dk] in the compute dtype
     def _attend(self, att: _Attention, h: torch.Tensor, enc: Optional[torch.Tensor], B: int, nq: int, Lk: int,
-                code: int) -> torch.Tensor:
+                code: int, enc_proj=None) -> torch.Tensor:
         dt = engine.torch_dtype(code)
         D = self.hidden_size
         hq = h.to(dt)                                      # [B*nq, D]: 2 rows per image
@@ -118,9 +118,21 @@ class IQM(nn.Module):
             # value projections of all Lk rows (2 x Lk x Dk x D MACs per image, reference model/iqm.py:116-121) become
             # two [nq*H, .] products.  b_k only shifts every score of a row by the same amount: softmax-invariant.
             qm = engine.head_expand(q, H, 1.0 / math.sqrt(D // H), code)                         # [B*nq*H, D]
-            qt = torch.empty(B * nq * H, enc.shape[-1], dtype=torch.float32, device=h.device)
+            kin = att.attention.key.weight.shape[1]
+            qt = torch.empty(B * nq * H, kin, dtype=torch.float32, device=h.device)
             engine.gemm(code, EPI_ACT_F32, qm, engine.CACHE.get(att.attention.key.weight, code, "transpose"), None, qt)
-            ebar = engine.cross_rows(qt, enc, B, nq * H, Lk, code)                               # [B*nq*H, Dk] fp32
+            if enc_proj is not None:
+                # the rows are enc = P x + b_p of raw rows x (AdaptedCLIP.visual_feature_proj on the concatenated levels,
+                # reference model/adapter.py:213-221): the same algebra once more -- (P^T qt) . x_j + const on the way
+                # in, P (sum_j p_j x_j) + b_p on the way out -- and the [B*Lk, .] projection is never computed
+                pw, pb = enc_proj
+                qx = torch.empty(B * nq * H, pw.shape[1], dtype=torch.float32, device=h.device)
+                engine.gemm(code, EPI_ACT_F32, qt.to(dt), engine.CACHE.get(pw, code, "transpose"), None, qx)
+                xbar = engine.cross_rows(qx, enc, B, nq * H, Lk, code)
+                ebar = torch.empty(B * nq * H, kin, dtype=torch.float32, device=h.device)
+                engine.gemm(code, EPI_ACT_F32, xbar.to(dt), engine.CACHE.get(pw, code), engine._f32c(pb), ebar)
+            else:
+                ebar = engine.cross_rows(qt, enc, B, nq * H, Lk, code)                           # [B*nq*H, Dk] fp32
             full = torch.empty(B * nq * H, D, dtype=torch.float32, device=h.device)
             engine.gemm(code, EPI_ACT_F32, ebar.to(dt), engine.CACHE.get(att.attention.value.weight, code),
                         engine._f32c(att.attention.value.bias), full)
@@ -144,9 +156,12 @@ class IQM(nn.Module):
 
     def forward(self, query_embeds: torch.Tensor, query_length: Optional[int] = None,
                 encoder_hidden_states: Optional[torch.Tensor] = None,
-                text_encoder_hidden_states: Optional[torch.Tensor] = None, code: Optional[int] = None, **_unused):
+                text_encoder_hidden_states: Optional[torch.Tensor] = None, code: Optional[int] = None,
+                encoder_proj=None, **_unused):
         """query_embeds fp32 [B, nq, D]; encoder_hidden_states [B, Lv, D] and text_encoder_hidden_states [B, Lt, D] in
-        the compute dtype (or fp32) -> IQMOutput.  reference model/iqm.py:572-673 with all masks zero."""
+        the compute dtype (or fp32) -> IQMOutput.  reference model/iqm.py:572-673 with all masks zero.
+        encoder_proj = (weight, bias): encoder_hidden_states are the rows BEFORE that Linear; it is folded into the
+        cross-attention (see _attend) instead of being applied to every row."""
         engine.require_gpu(query_embeds, "IQM")
         if code is None:
             code = engine.dtype_code(getattr(self, "precision", "fp32"))
@@ -161,7 +176,7 @@ class IQM(nn.Module):
         h = engine.residual_layernorm(engine._f32c(query_embeds).reshape(B * nq, D), None, self.layernorm, self.eps)
         for layer in self.encoder.layer:
             a = self._attend(layer.attention, h, None, B, nq, nq, code)
-            c = self._attend(layer.crossattention, a, vis, B, nq, Lv, code)
+            c = self._attend(layer.crossattention, a, vis, B, nq, Lv, code, enc_proj=encoder_proj)
             t = self._attend(layer.text_crossattention, c, txt, B, nq, Lt, code)
             mix = engine.combine3(a, c, t, 0.4, 0.3, 0.3)                                            # iqm.py:311-315
             inter = torch.empty(B * nq, layer.intermediate_query.dense.weight.shape[0], dtype=dt, device=h.device)

@@ -160,7 +160,7 @@ def _build(dev, precision):
 # measured on MI355X (profiles/r03_parity_errors.json): fp32 and fp16x2 1e-7...2e-7, plain fp16 (16-bit tower AND 16-bit
 # IQM layers) 1.2e-5...1.5e-5; asserted with a factor ~3-10 of headroom, i.e. at <= 6 % of the signal's std for fp16
 IQM_GRID_TOL = {"fp32": 2e-6, "fp16x2": 2e-6, "fp16": 5e-5}
-IQM_HID_TOL = {"fp32": (2e-4, 1e-3), "fp16x2": (5e-4, 1e-3), "fp16": (2e-2, 2e-2)}
+IQM_HID_TOL = {"fp32": (2e-4, 1e-3), "fp16x2": (1.5e-3, 1e-3), "fp16": (2e-2, 2e-2)}   # fp16x2: measured 6.4e-4 (the tower's error; the branch itself runs in fp32)
 
 
 def _record(name, a, b):
