@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 // L = 77, the V-V path over the batch axis) have too few keys per row for the averaging argument, and cost nothing.
 template <bool LOG2Q, bool VL>
 __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __restrict__ qkv, f16* __restrict__ ctx, int L, int H,
-                                                         int causal, int nqt, int total, int per_xcd) {
+                                                         int causal, int nqt, int total, int per_xcd, bool hi8) {
   typedef f16x8 vec8;
   typedef f16x4 vec4;
   typedef short i16x8 __attribute__((ext_vector_type(8)));
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
         *(vec4*)(dst + col) = vh;
         uint8_t* p8 = (uint8_t*)(dst - head * 64 + D) + head * 64;   // e4m3 planes of this row: lo8 at 2D bytes, hi8 at 3D
         *(uint32_t*)(p8 + col) = l8;
-        *(uint32_t*)(p8 + D + col) = h8;
+        if (hi8) *(uint32_t*)(p8 + D + col) = h8;
       }
   }
 }
@@ -1979,13 +1979,13 @@ bool set_attn_variant(int v) {
 }
 
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
-                      hipStream_t s) {
+                      hipStream_t s, bool hi8) {
   if (dtype == AACLIP_F16X2) {   // split fp16 rows in, split fp16 rows out
     const int nqt = (L + 127) / 128;
     const long totl = (long)nqt * H * B;
     const int per_xcd = (int)((totl + 7) / 8), tot = (int)totl;
     dim3 g((unsigned)(per_xcd * 8));
-#define ATTN_LAUNCH_S(LQ, VLO) hipLaunchKernelGGL((attn16s_kernel<LQ, VLO>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd)
+#define ATTN_LAUNCH_S(LQ, VLO) hipLaunchKernelGGL((attn16s_kernel<LQ, VLO>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd, hi8)
     if (L >= 512) {   // long rows: v's lo half is not read (see attn16s_kernel)
       if (log2q) ATTN_LAUNCH_S(true, false); else ATTN_LAUNCH_S(false, false);
     } else {

@@ -385,7 +385,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
   const float qscale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
   const char* ctx = narrow;
   if (attn_mode == AACLIP_ATTN_VV_BATCH) {
-    { ProfScope ps(0, s); launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s); }
+    { ProfScope ps(0, s); launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s, !(ex & AACLIP_EXACT16_QKV)); }
     // only the value third of in_proj is needed; v lives behind the packed q|k|v buffer inside `big`
     char* vbuf = big + (size_t)rows * 3 * D * es;
     p.A = narrow; p.lda = sw * D; p.M = M; p.N = D; p.K = D;
@@ -397,7 +397,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     {
       ProfScope ps(2, s);
       launch_vv_spread(dtype, vbuf, big, B, L, D, qscale, s);
-      launch_attention(dtype, big, narrow, /*batches=*/L, /*sequence=*/B, H, 0, log2q, s);
+      launch_attention(dtype, big, narrow, /*batches=*/L, /*sequence=*/B, H, 0, log2q, s, !(ex & AACLIP_EXACT16_OUT));
       launch_vv_regroup(dtype, narrow, vbuf, B, L, D, s);
     }
     ctx = vbuf;
@@ -409,10 +409,10 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
       p.A = x16; p.W = w->qkv_w_fold; p.bias = w->qkv_fold_b; p.row_ab = rowab; p.col_s = w->qkv_fold_s;
     } else {
       ProfScope ps(0, s);
-      launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s);
+      launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s, !(ex & AACLIP_EXACT16_QKV));
     }
     { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
-    { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s); }
+    { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s, !(ex & AACLIP_EXACT16_OUT)); }
   }
   memset(&p, 0, sizeof(p));
   p.A = ctx; p.lda = sw * D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;
@@ -424,6 +424,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
   memset(&fc, 0, sizeof(fc));
   fc.lda = sw * D; fc.M = M; fc.N = F; fc.K = D; fc.out = big; fc.ldc = sw * F;
   fc.A = narrow; fc.W = w->fc_w; fc.bias = w->fc_b; fc.w_exact16 = ex & AACLIP_EXACT16_FC;
+  fc.out_no_hi8 = (ex & AACLIP_EXACT16_PROJ) ? 1 : 0;   // c_proj is the only reader of the GELU rows
   const bool fold2 = folding && w->fc_w_fold && w->fc_fold_s && w->fc_fold_b && gemm_routes_to_256t(dtype, p) &&
                      gemm_routes_to_256t(dtype, fc);
   if (fold2) {
@@ -438,7 +439,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     fc.A = x16; fc.W = w->fc_w_fold; fc.bias = w->fc_fold_b; fc.row_ab = rowab; fc.col_s = w->fc_fold_s;
   } else {
     ProfScope ps(0, s);
-    launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s);
+    launch_layernorm(dtype, x, w->ln2_w, w->ln2_b, narrow, rows, D, 1e-5f, s, !(ex & AACLIP_EXACT16_FC));
   }
   { ProfScope ps(4, s); launch_gemm(dtype, EPI_BIAS_GELU, fc, s); }
   memset(&p, 0, sizeof(p));
@@ -464,7 +465,7 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
     if (emit) {
       a_in = x16;
     } else if (dtype == AACLIP_F16X2) {
-      launch_split_rows(x, narrow, rows, D, s);
+      launch_split_rows(x, narrow, rows, D, s, !(ex & AACLIP_EXACT16_ADAPTER));
       a_in = narrow;
     } else if (dtype != AACLIP_F32) {
       launch_cast_rows(dtype, x, narrow, rows * D, s);

@@ -35,7 +35,7 @@ AACLIP_DEV void store16(const GemmParams& p, int row, int col, float v) {
     } else {
       uint8_t* o8 = (uint8_t*)(o + p.N);
       o8[col] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_LO_EXP>(v - (float)hi, 0.f, 0.f, 0.f);
-      o8[p.N + col] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_HI_EXP>(v, 0.f, 0.f, 0.f);
+      if (!p.out_no_hi8) o8[p.N + col] = (uint8_t)pack_e4m3x4<SPLIT8_ACT_HI_EXP>(v, 0.f, 0.f, 0.f);
     }
   } else {
     ((TOut*)p.out)[(long)row * p.ldc + col] = from_float<TOut>(v);

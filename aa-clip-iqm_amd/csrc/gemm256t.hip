@@ -150,7 +150,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
             } else {
               // chunk c < 4: bytes [16c, 16c+16) of this wave's 64 lo8 columns; c >= 4: of its hi8 columns
               char* o8 = (char*)orow + 2 * p.N + (c >> 2) * p.N + n_base + (c & 3) * 16;
-              ST_OUT((u32x4*)o8, vl);
+              if (c < 4 || !p.out_no_hi8) ST_OUT((u32x4*)o8, vl);
             }
           }
         } else {

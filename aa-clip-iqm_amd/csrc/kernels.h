@@ -32,6 +32,7 @@ struct GemmParams {
   // or, with w_exact16, [N, K] (the weight is exact in fp16: the Ah.Wl product is skipped); 16-bit outputs are split
   // rows too ([M, >= 2N], ldc = row stride, lo plane N columns after the hi plane).
   int w_exact16;
+  int out_no_hi8;             // EPI_BIAS_GELU, split fp16: the consumer's weight is exact in fp16 -- skip the hi8 plane
 };
 
 const char* gemm_check(int dtype, int epi, const GemmParams& p);
@@ -64,12 +65,14 @@ void read_attn_stamps(unsigned long long* out9, int reset);   // -DATTN_STAMP bu
 // fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]
 // log2q != 0: q is pre-multiplied by log2(e) as well (16-bit kernels only)
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
-                      hipStream_t s);
+                      hipStream_t s, bool hi8 = true);
 
 // row ops (rowops.hip); D in {256, 768, 1024}
 const char* row_width_check(int D);
+// hi8 = false (split fp16 only): do not write the hi8 plane of the split8 rows -- for a consumer whose weight is exact
+// in fp16 and therefore never reads it (common.h); the same flag exists on every producer of split8 rows
 void launch_layernorm(int out_dtype, const float* x, const float* w, const float* b, void* out, long rows, int D,
-                      float eps, hipStream_t s);
+                      float eps, hipStream_t s, bool hi8 = true);
 void launch_adapter_mix(float* x, const float* a, long rows, int D, float weight, hipStream_t s);
 void launch_adapter_mix_fold(int dtype, float* x, const float* a, long rows, int D, float weight, void* out16,
                              float* rowab, hipStream_t s);   // also emits the 16-bit rows and (rstd, -mean*rstd)
@@ -93,7 +96,7 @@ void launch_blur_upsample(const float* pre, float* out, int B, int g, int S, int
                           hipStream_t s);
 void launch_upsample_softmax2(const float* scores, float* out, int B, int g, int S, hipStream_t s);
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s);
-void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s);   // fp32 [rows, D] -> split fp16 [rows, 2D]
+void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s, bool hi8 = true);   // fp32 [rows, D] -> split fp16 [rows, 2D]
 // LayerNorm folding: [M][slots][2] partial (sum, sumsq) -> [M][2] (rstd, -mean*rstd)
 void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s);
 bool gemm_routes_to_256t(int dtype, const GemmParams& p);   // launch_gemm will run a kernel with the folding epilogue

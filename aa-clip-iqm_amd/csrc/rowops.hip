@@ -37,7 +37,9 @@ AACLIP_DEV void store4<bf16>(bf16* p, f32x4 v) {
 // two-pass statistics in registers; out may alias x when T == float.
 // split8 row (AACLIP_F16X2, common.h): 4 values at column `col` of a row of logical width `width` starting at `row`:
 // hi plane (fp16), then the lo8 and hi8 planes (e4m3, one byte per element)
-AACLIP_DEV void store4_split(f16* row, int col, f32x4 v, int width) {
+// hi8 = false: the hi8 plane is not written (its only reader is the Ah8 . Wl8 correction tile, which a product whose
+// weight is exact in fp16 skips)
+AACLIP_DEV void store4_split(f16* row, int col, f32x4 v, int width, bool hi8 = true) {
   const float vv[4] = {v[0], v[1], v[2], v[3]};
   f16x4 hi;
   uint32_t l8, h8;
@@ -45,12 +47,13 @@ AACLIP_DEV void store4_split(f16* row, int col, f32x4 v, int width) {
   *(f16x4*)(row + col) = hi;
   uint8_t* p8 = (uint8_t*)(row + width);
   *(uint32_t*)(p8 + col) = l8;
-  *(uint32_t*)(p8 + width + col) = h8;
+  if (hi8) *(uint32_t*)(p8 + width + col) = h8;
 }
 
 template <typename T, int NCH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, T* out, long rows, float eps) {
+                                                        const float* __restrict__ b, T* out, long rows, float eps,
+                                                        bool hi8 = true) {
   constexpr int D = NCH * 256;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     f32x4 g = *(const f32x4*)(w + col), bb = *(const f32x4*)(b + col), y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
-    if constexpr (SPLIT) store4_split(out + row * 2 * D, col, y, D);
+    if constexpr (SPLIT) store4_split(out + row * 2 * D, col, y, D, hi8);
     else store4<T>(out + row * D + col, y);
   }
 }
@@ -94,19 +97,19 @@ static void ln_dispatch(const float* x, const float* w, const float* b, T* out, 
 }
 
 static void ln_dispatch_split(const float* x, const float* w, const float* b, f16* out, long rows, int D, float eps,
-                              hipStream_t s) {
+                              hipStream_t s, bool hi8) {
   dim3 g((unsigned)((rows + 3) / 4));
   switch (D / 256) {
-    case 1: hipLaunchKernelGGL((layernorm_kernel<f16, 1, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
-    case 2: hipLaunchKernelGGL((layernorm_kernel<f16, 2, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
-    case 3: hipLaunchKernelGGL((layernorm_kernel<f16, 3, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
-    case 4: hipLaunchKernelGGL((layernorm_kernel<f16, 4, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps); break;
+    case 1: hipLaunchKernelGGL((layernorm_kernel<f16, 1, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps, hi8); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<f16, 2, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps, hi8); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<f16, 3, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps, hi8); break;
+    case 4: hipLaunchKernelGGL((layernorm_kernel<f16, 4, true>), g, dim3(256), 0, s, x, w, b, out, rows, eps, hi8); break;
   }
 }
 
 void launch_layernorm(int out_dtype, const float* x, const float* w, const float* b, void* out, long rows, int D,
-                      float eps, hipStream_t s) {
-  if (out_dtype == AACLIP_F16X2) ln_dispatch_split(x, w, b, (f16*)out, rows, D, eps, s);
+                      float eps, hipStream_t s, bool hi8) {
+  if (out_dtype == AACLIP_F16X2) ln_dispatch_split(x, w, b, (f16*)out, rows, D, eps, s, hi8);
   else if (out_dtype == AACLIP_F32) ln_dispatch<float>(x, w, b, (float*)out, rows, D, eps, s);
   else if (out_dtype == AACLIP_F16) ln_dispatch<f16>(x, w, b, (f16*)out, rows, D, eps, s);
   else ln_dispatch<bf16>(x, w, b, (bf16*)out, rows, D, eps, s);
@@ -404,18 +407,18 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
 }
 // fp32 rows [rows, D] -> split8 rows [rows, 2D halves]
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, f16* __restrict__ dst, long n4,
-                                                         int d4) {
+                                                         int d4, bool hi8) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const long r = i / d4;
     const int c = (int)(i - r * d4) * 4;
-    store4_split(dst + r * 8 * d4, c, *(const f32x4*)(src + i * 4), 4 * d4);
+    store4_split(dst + r * 8 * d4, c, *(const f32x4*)(src + i * 4), 4 * d4, hi8);
   }
 }
-void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s) {
+void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_t s, bool hi8) {
   const long n4 = rows * D / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, (f16*)dst, n4, D / 4);
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, (f16*)dst, n4, D / 4, hi8);
 }
 void launch_cast_rows(int dtype, const float* src, void* dst, long n, hipStream_t s) {
   const long n4 = n / 4;
