@@ -173,6 +173,27 @@ def test_gemm_split_epilogues(dev, shape):
     assert_close(o32, A.double() @ Wh.double().t(), ea, er, "fp16-exact weight, 4 planes")
 
 
+def test_gemm_split_ragged_shapes_sweep(dev):
+    """Seeded sweep over row counts around the kernel switch (M = 4096) and ragged last tiles (the 256-tile split kernel
+    reads rows past M through the buffer descriptor's bounds instead of clamping), K tile-pair counts 1...9, N of one to
+    five 128- / 256-column tiles: fp32-out result against fp64, and rows [M, M + 3) of an over-allocated output untouched."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(20260104)
+    cases = [(4095, 256, 128), (4096, 256, 128), (4097, 512, 256), (4351, 256, 1152), (4352, 768, 384), (4609, 1280, 640),
+             (8191, 256, 512), (1, 128, 128), (127, 384, 256), (129, 128, 896), (300, 640, 1024)]
+    for _ in range(6):
+        M = int(torch.randint(4096, 9000, (1,), generator=g))
+        cases.append((M, 256 * int(torch.randint(1, 4, (1,), generator=g)), 128 * int(torch.randint(1, 10, (1,), generator=g))))
+    for M, N, K in cases:
+        A = synth.randn(f"t.sw.a{M}", (M, K), 1.0, 3)
+        W = synth.randn(f"t.sw.w{N}", (N, K), K ** -0.5, 3)
+        Ad, Wd = engine.split_rows(A.to(dev)), engine.split_rows(W.to(dev), weight=True)
+        out = torch.full((M + 3, N), 7.5, dtype=torch.float32, device=dev)
+        _gemm(lib, dev, _lib.EPI_ACT_F32, Ad, Wd, None, out[:M], K)
+        assert_close(out[:M], A.double() @ W.double().t(), 3e-4, 1e-4, f"sweep {(M, N, K)}")
+        assert bool((out[M:] == 7.5).all()), f"rows past M written for {(M, N, K)}"
+
+
 def _attn_ref(qkv, B, L, H, causal):
     D = H * 64
     q, k, v = qkv.double().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
