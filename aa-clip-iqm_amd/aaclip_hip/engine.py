@@ -59,8 +59,9 @@ SPLIT8_ACT_LO_EXP, SPLIT8_ACT_HI_EXP, SPLIT8_W_HI_EXP, SPLIT8_W_LO_EXP = 10, 0, 
 
 
 def _e4m3_bytes(v: torch.Tensor, exp: int) -> torch.Tensor:
-    """fp32 -> e4m3 (OCP e4m3fn) bytes of v * 2^exp, clamped to +-448; converted on the host (load-time work)."""
-    x = (v.detach().float().cpu() * float(2 ** exp)).clamp_(-448.0, 448.0)
+    """fp32 -> e4m3 (OCP e4m3fn) bytes of v * 2^exp, clamped to +-448, on v's own device (torch's conversion gives the
+    same bytes on the host and on the MI355X; load-time work)."""
+    x = (v.detach().float() * float(2 ** exp)).clamp_(-448.0, 448.0)
     return x.to(torch.float8_e4m3fn).view(torch.uint8)
 
 
@@ -78,8 +79,7 @@ def split_rows(t: torch.Tensor, weight: bool = False, exact: bool = False) -> to
     of AACLIP_F16X2 (lo8 = e4m3((v - hi) * 2^10), hi8 = e4m3(v) for activations; weights: [Wh][e4m3(W * 2^6)]
     [e4m3((W - Wh) * 2^17)], the last plane dropped when `exact`).  Load-time / caller-side operand preparation, like
     the .to(dtype) of the other modes; the hot path's own split rows are written by the kernels' epilogues."""
-    dev = t.device
-    v = t.detach().float().cpu()
+    v = t.detach().float()
     hi = v.to(torch.float16)
     lo = v - hi.float()
     planes = [hi.contiguous().view(torch.uint8).reshape(v.shape[0], -1)]
@@ -89,7 +89,7 @@ def split_rows(t: torch.Tensor, weight: bool = False, exact: bool = False) -> to
             planes.append(_e4m3_bytes(lo, SPLIT8_W_LO_EXP))
     else:
         planes += [_e4m3_bytes(lo, SPLIT8_ACT_LO_EXP), _e4m3_bytes(v, SPLIT8_ACT_HI_EXP)]
-    return torch.cat(planes, dim=1).contiguous().to(dev)
+    return torch.cat(planes, dim=1).contiguous()
 
 
 def join_split8(t: torch.Tensor, C: int) -> torch.Tensor:

@@ -424,3 +424,33 @@ def test_reference_callers_names_exist_in_the_build():
     U.setup_seed(3)
     a = torch.nn.functional.normalize(torch.randn(5, 8), dim=-1)
     assert torch.allclose(U.cos_sim(a[0], a), a @ a[0]) and U.cos_sim(a, a).shape == (5, 5)
+
+
+def test_split_row_formats_on_the_host():
+    """engine.split_rows / split16_rows (the AACLIP_F16X2 operand formats, include/aaclip.h): plane layout, scales and
+    what a product sees of a value; weights exact in fp16 take the 3-plane form only when asked and K % 256 == 0."""
+    x = synth.randn("t.split.host", (5, 256), 2.0, 1)
+    s8 = engine.split_rows(x)
+    assert s8.dtype == torch.uint8 and s8.shape == (5, 1024)
+    hi = s8[:, :512].contiguous().view(torch.float16)
+    assert torch.equal(hi, x.half())
+    lo8 = s8[:, 512:768].contiguous().view(torch.float8_e4m3fn).float() / 1024.0
+    hi8 = s8[:, 768:].contiguous().view(torch.float8_e4m3fn).float()
+    assert float(((hi.float() + lo8 - x).abs() / (x.abs() * 2.0 ** -15 + 2.0 ** -19)).max()) <= 1.0
+    assert float(((hi8 - x).abs() / (x.abs() * 2.0 ** -4 + 2.0 ** -9)).max()) <= 1.0
+    assert torch.allclose(engine.join_split8(s8, 256), (hi.float() + lo8).double())
+    s16 = engine.split16_rows(x)
+    assert s16.dtype == torch.float16 and s16.shape == (5, 512)
+    assert float((s16[:, :256].double() + s16[:, 256:].double() - x.double()).abs().max()) <= 2.0 ** -20
+    w = engine.split_rows(x, weight=True)
+    wh8 = w[:, 512:768].contiguous().view(torch.float8_e4m3fn).float() / 64.0
+    assert float(((wh8 - x).abs() / (x.abs() * 2.0 ** -4 + 2.0 ** -15)).max()) <= 1.0
+    # saturation instead of NaN beyond e4m3's range (the hardware conversion would return NaN: the kernels clamp too)
+    big = engine.split_rows(torch.tensor([[1000.0, -1e6] + [0.0] * 254]))
+    assert float(big[:, 768:].contiguous().view(torch.float8_e4m3fn).float().abs().max()) == 448.0
+    p = torch.nn.Parameter(x.half().float().repeat(1, 1))
+    assert engine.CACHE.get(p, _lib.F16X2, "plain+exact").shape == (5, 768)        # exact in fp16, K = 256
+    assert engine.CACHE.get(p, _lib.F16X2, "plain").shape == (5, 1024)
+    q = torch.nn.Parameter(x[:, :128].half().float().contiguous())
+    assert engine.CACHE.get(q, _lib.F16X2, "plain+exact").shape == (5, 512)        # K = 128: pairs of K tiles, no 3-plane form
+    assert engine.dtype_code("fp16x2") == _lib.F16X2 and engine.plain_code(_lib.F16X2) == _lib.F32
