@@ -361,6 +361,11 @@ def run_rank(args):
             result.update({
                 "whole_path_tflops": round(value * gflop_img / 1e3, 1),
                 "whole_path_frac_of_mfma_peak": round(value * gflop_img / 1e3 / (peak * n_gpus), 4),
+                # share of the fp16 MFMA pipe's time the path keeps busy = algorithmic fraction x the mode's MFMA time
+                # multiple (fp16x2: GEMMs 82 % of the flops at 2.0 -- 1.5 with fp16-exact weights --, attention 18 % at 2.0)
+                "whole_path_mfma_time_frac": round(value * gflop_img / 1e3 / (peak * n_gpus) * (
+                    ((0.82 * (1.5 if args.clip_weights == "fp16" else 2.0) + 0.18 * 2.0) if args.precision == "fp16x2"
+                     else 1.0)), 4),
                 "roofline": {
                     "kernel": kname + f" (mlp.c_fc, M={B}*1370, N=4096, K=1024)",
                     "bound": "mfma",
