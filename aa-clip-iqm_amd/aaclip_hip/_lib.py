@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AACLIP_LIB") or os.path.join(_HERE, "libaaclip_hip.so")   # AACLIP_LIB: experiment builds
 MEASURE_LIB_PATH = os.path.join(_HERE, "libaaclip_hip_measure.so")   # `make measure`: A/B variants, ablations, stamps
-ABI_VERSION = 4   # include/aaclip.h AACLIP_ABI_VERSION this binding was written against
+ABI_VERSION = 5   # include/aaclip.h AACLIP_ABI_VERSION this binding was written against
 
 F32, F16, BF16, F16X2 = 0, 1, 2, 3   # F16X2: split fp16 (hi + lo pairs), include/aaclip.h
 EXACT16_QKV, EXACT16_OUT, EXACT16_FC, EXACT16_PROJ, EXACT16_ADAPTER = 1, 2, 4, 8, 16
@@ -48,6 +48,7 @@ SIGNATURES = {
     "aaclip_blocks_to": (_i, [_vp, _vp, C.POINTER(BlockWeights), _i, _f] + [_i] * 7 + [_vp, _sz, _vp]),
     "aaclip_blocks_taps": (_i, [_vp, C.POINTER(_vp), C.POINTER(BlockWeights), _i, _f] + [_i] * 7 + [_vp, _sz, _vp]),
     "aaclip_tap_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
+    "aaclip_tap_head_keep_rows": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "aaclip_det_head": (_i, [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "aaclip_anomaly_map": (_i, [C.POINTER(_vp), _i, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "aaclip_similarity_map_train": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "aaclip_small_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "aaclip_cross_rows_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "aaclip_cross_rows": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "aaclip_cross_rows_levels_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "aaclip_cross_rows_levels": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _l, _vp, _sz, _vp]),
     "aaclip_head_expand": (_i, [_i, _vp, _vp, _l, _i, _i, _f, _vp]),
     "aaclip_head_diag": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "aaclip_residual_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),

@@ -381,8 +381,10 @@ def run_blocks(x: torch.Tensor, blocks: Sequence, B: int, L: int, heads: int, co
 
 
 def tap_head(x: torch.Tensor, ln_post, proj_weight: torch.Tensor, act: bool, B: int, L: int, code: int,
-             det_weight: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """reference model/adapter.py:171-184 -> (seg [B,L-1,E] unit rows, det [B,E] or None)."""
+             det_weight: Optional[torch.Tensor] = None, keep_rows: bool = False):
+    """reference model/adapter.py:171-184 -> (seg [B,L-1,E] unit rows, det [B,E] or None).
+    keep_rows: also return ln_post(x) [B*L, .] in the layout of `code` (uint8 [B*L, 4D] split8 rows under fp16x2): the
+    IQM branch reads the same rows (reference model/adapter.py:205-208)."""
     require_gpu(x, "tap_head")
     lib = _lib.load()
     D, E = x.shape[1], proj_weight.shape[0]
@@ -392,6 +394,13 @@ def tap_head(x: torch.Tensor, ln_post, proj_weight: torch.Tensor, act: bool, B: 
     dw = CACHE.get(det_weight, code) if det_weight is not None else None
     lw, lb = _f32c(ln_post.weight), _f32c(ln_post.bias)
     ws = Workspace.for_rows(x.device, code, B * L, D, 0, E)
+    if keep_rows:
+        rows = (torch.empty(B * L, 4 * D, dtype=torch.uint8, device=x.device) if code == F16X2
+                else torch.empty(B * L, D, dtype=torch_dtype(code), device=x.device))
+        _lib.check(lib.aaclip_tap_head_keep_rows(x.data_ptr(), lw.data_ptr(), lb.data_ptr(), pw.data_ptr(), int(act),
+                                                 seg.data_ptr(), _ptr(dw), _ptr(det), rows.data_ptr(), B, L, D, E, code,
+                                                 ws.data_ptr(), ws.numel(), _stream(x.device)), "tap_head_keep_rows")
+        return seg, det, rows
     _lib.check(lib.aaclip_tap_head(x.data_ptr(), lw.data_ptr(), lb.data_ptr(), pw.data_ptr(), int(act),
                                    seg.data_ptr(), _ptr(dw), _ptr(det), B, L, D, E, code, ws.data_ptr(), ws.numel(),
                                    _stream(x.device)), "tap_head")
@@ -617,6 +626,31 @@ def cross_rows(qt: torch.Tensor, x: torch.Tensor, B: int, R: int, Lk: int, x_cod
     ws = Workspace.get(x.device, lib.aaclip_cross_rows_workspace_bytes(B, R, Lk, Dk) + 256)
     _lib.check(lib.aaclip_cross_rows(x_code, qt.data_ptr(), x.data_ptr(), out.data_ptr(), B, R, Lk, Dk, ws.data_ptr(),
                                      ws.numel(), _stream(x.device)), "cross_rows")
+    return out
+
+
+def cross_rows_levels(qt: torch.Tensor, levels, B: int, R: int, rows_per_image: int, row0: int, Lk: int,
+                      Dk: int) -> torch.Tensor:
+    """include/aaclip.h aaclip_cross_rows_levels.  qt fp32 [B*R, nseg*Dk]; levels = row buffers, one per segment: fp16 /
+    bf16 [B*rows_per_image, Dk], or uint8 split8 rows [B*rows_per_image, 4*Dk] (their fp16 halves are read)."""
+    require_gpu(qt, "cross_rows_levels")
+    lib = _lib.load()
+    nseg = len(levels)
+    x0 = levels[0]
+    if x0.dtype == torch.uint8:
+        xc, ldx = _lib.F16, x0.shape[1] // 2
+    else:
+        xc, ldx = {torch.float16: F16, torch.bfloat16: BF16}[x0.dtype], x0.shape[1]
+    for x in levels:
+        if x.dtype != x0.dtype or x.shape != x0.shape or not x.is_contiguous() or x.device != qt.device:
+            raise ValueError("cross_rows_levels: the level buffers must agree in dtype, shape and device")
+    if qt.shape != (B * R, nseg * Dk) or qt.dtype != torch.float32 or not qt.is_contiguous():
+        raise ValueError("cross_rows_levels: qt must be contiguous fp32 [B*R, nseg*Dk]")
+    ptrs = (C.c_void_p * nseg)(*[x.data_ptr() for x in levels])
+    out = torch.empty(B * R, nseg * Dk, dtype=torch.float32, device=qt.device)
+    ws = Workspace.get(qt.device, lib.aaclip_cross_rows_levels_workspace_bytes(B, nseg, Lk, Dk) + 256)
+    _lib.check(lib.aaclip_cross_rows_levels(xc, qt.data_ptr(), ptrs, nseg, out.data_ptr(), B, R, rows_per_image, row0, Lk,
+                                            Dk, ldx, ws.data_ptr(), ws.numel(), _stream(qt.device)), "cross_rows_levels")
     return out
 
 

@@ -258,6 +258,26 @@ int aaclip_cross_rows(int x_dtype, const float* qt, const void* x, float* out, i
   return finish("cross_rows");
 }
 
+size_t aaclip_cross_rows_levels_workspace_bytes(int B, int nseg, int Lk, int Dk) {
+  if (B < 1 || nseg < 1 || Lk < 1 || Dk < 1) return 0;
+  return cross_rows_levels_ws_bytes(B, nseg, Lk, Dk);
+}
+
+int aaclip_cross_rows_levels(int x_dtype, const float* qt, const void* const* x, int nseg, float* out, int B, int R,
+                             int rows_per_image, int row0, int Lk, int Dk, long ldx, void* ws, size_t ws_bytes,
+                             void* stream) {
+  REQUIRE(qt && x && out && ws, "cross_rows_levels: null pointer");
+  REQUIRE(B > 0 && B <= 65535, "cross_rows_levels: bad batch");
+  const char* m = cross_rows_levels_check(x_dtype, R, nseg, Lk, Dk, ldx);
+  if (m) return fail(-1, m);
+  REQUIRE(row0 >= 0 && rows_per_image >= row0 + Lk, "cross_rows_levels: the keys [row0, row0 + Lk) must lie inside an image's rows");
+  REQUIRE((long)rows_per_image * ldx * 2 < (1L << 31), "cross_rows_levels: an image's rows must span < 2 GiB");
+  REQUIRE(ws_bytes >= cross_rows_levels_ws_bytes(B, nseg, Lk, Dk), "cross_rows_levels: workspace too small");
+  for (int i = 0; i < nseg; ++i) REQUIRE(x[i] && ((uintptr_t)x[i] & 15) == 0, "cross_rows_levels: segment pointers must be 16-byte aligned");
+  launch_cross_rows_levels(x_dtype, qt, x, nseg, out, ws, B, R, rows_per_image, row0, Lk, Dk, ldx, (hipStream_t)stream);
+  return finish("cross_rows_levels");
+}
+
 int aaclip_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, void* stream) {
   REQUIRE(plain_dtype_ok(dtype), "head_expand: bad dtype (fp32, fp16 or bf16)");
   REQUIRE(q && qm && rows > 0 && H > 0 && D > 0 && D % H == 0, "head_expand: bad arguments");
@@ -576,9 +596,9 @@ static int head_common(const float* x, const float* ln_w, const float* ln_b, int
   return 0;
 }
 
-int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
-                    float* seg_out, const void* det_w, float* det_out, int B, int L, int D, int E, int dtype, void* ws,
-                    size_t ws_bytes, void* stream) {
+static int tap_head_impl(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
+                         float* seg_out, const void* det_w, float* det_out, void* ln_rows_out, int B, int L, int D, int E,
+                         int dtype, void* ws, size_t ws_bytes, void* stream) {
   char *narrow, *big, *rowf;
   int rc = head_common(x, ln_post_w, ln_post_b, B, L, D, E, dtype, ws, ws_bytes, &narrow, &big, &rowf);
   if (rc) return rc;
@@ -586,10 +606,11 @@ int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post
   REQUIRE(!det_w || det_out, "tap_head: det_out missing");
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)B * L;
-  launch_layernorm(dtype, x, ln_post_w, ln_post_b, narrow, rows, D, 1e-5f, s);
+  char* ln = ln_rows_out ? (char*)ln_rows_out : narrow;   // the LayerNorm'ed rows, kept for the caller if asked
+  launch_layernorm(dtype, x, ln_post_w, ln_post_b, ln, rows, D, 1e-5f, s);
   GemmParams p;
   memset(&p, 0, sizeof(p));
-  p.A = narrow; p.lda = split_w(dtype) * D; p.W = proj_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
+  p.A = ln; p.lda = split_w(dtype) * D; p.W = proj_w; p.M = (int)rows; p.N = E; p.K = D; p.out = big; p.ldc = E; p.act = act;
   launch_gemm(dtype, EPI_ACT_F32, p, s);
   launch_normalize_rows((const float*)big, seg_out, B, L, 1, E, s);
   if (det_w) {
@@ -598,6 +619,21 @@ int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post
     launch_det_mean((const float*)big, (float*)narrow, (size_t)(big - narrow) / 4, det_out, B, L, 1, E, s);   // narrow is free after the GEMM
   }
   return finish("tap_head");
+}
+
+int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
+                    float* seg_out, const void* det_w, float* det_out, int B, int L, int D, int E, int dtype, void* ws,
+                    size_t ws_bytes, void* stream) {
+  return tap_head_impl(x, ln_post_w, ln_post_b, proj_w, act, seg_out, det_w, det_out, nullptr, B, L, D, E, dtype, ws, ws_bytes,
+                       stream);
+}
+
+int aaclip_tap_head_keep_rows(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
+                              float* seg_out, const void* det_w, float* det_out, void* ln_rows_out, int B, int L, int D,
+                              int E, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  REQUIRE(ln_rows_out, "tap_head_keep_rows: null pointer");
+  return tap_head_impl(x, ln_post_w, ln_post_b, proj_w, act, seg_out, det_w, det_out, ln_rows_out, B, L, D, E, dtype, ws,
+                       ws_bytes, stream);
 }
 
 int aaclip_det_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* det_w, int act,

@@ -1004,15 +1004,10 @@ template <> struct FragPair<f16, true> {
     for (int e = 0; e < 4; ++e) v[4 * ks + e] = x[e];
   }
 };
-AACLIP_DEV f32x4 mma_e4m3w(const FragPair<f16, true>& a, const FragPair<f16, true>& b, f32x4 c, int sa, int sb) {
-  // inline asm with the accumulator tied in place: through the builtin hipcc gives many of these MFMAs a destination
-  // tuple different from their C operand (copies back, spills).  No result of a correction tile is read before the
-  // next s_barrier, so no wait states are needed here; the epilogue waits (see the end of the K loop).
-  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
-               : "+v"(c) : "v"(a.v), "v"(b.v), "v"(sa), "v"(sb));
-  return c;
-}
-// The same with both scale bytes taken from ONE register (the kernel is at its register limit): `sc` holds
+// The block-scaled e4m3 MFMA of a correction tile (KIND 1: Al8 . Wh8, KIND 2: Ah8 . Wl8), from inline asm with the
+// accumulator tied in place: through the builtin hipcc gives many of these MFMAs a destination tuple different from
+// their C operand (copies back, spills).  No result of a correction tile is read before the next s_barrier, so no wait
+// states are needed here.  Both scale bytes come from ONE register (the kernel is at its register limit): `sc` holds
 // [byte 0: T1 act, byte 1: T1 weight, byte 2: T2 weight, byte 3: T2 act]; op_sel / op_sel_hi pick the byte per operand.
 template <int KIND>
 AACLIP_DEV f32x4 mma_e4m3k(const FragPair<f16, true>& w, const FragPair<f16, true>& a, f32x4 c, int sc) {
@@ -1025,7 +1020,6 @@ AACLIP_DEV f32x4 mma_e4m3k(const FragPair<f16, true>& w, const FragPair<f16, tru
   return c;
 }
 template <int KIND, typename T> AACLIP_DEV f32x4 mma_e4m3k(const FragPair<T, false>&, const FragPair<T, false>&, f32x4 c, int) { return c; }
-template <typename T> AACLIP_DEV f32x4 mma_e4m3w(const FragPair<T, false>&, const FragPair<T, false>&, f32x4 c, int, int) { return c; }
 
 template <typename T, int EPI, int NP = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {

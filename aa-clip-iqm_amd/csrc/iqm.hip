@@ -13,6 +13,7 @@
 //                        (align_corners=False) upsampling, level sum and the 0.6 / 0.4 fusion with the text map
 #include "common.h"
 #include "kernels.h"
+#include "mma16.h"
 
 namespace aaclip {
 
@@ -300,6 +301,240 @@ void launch_cross_rows(int x_dtype, const float* qt, const void* x, float* out, 
   if (x_dtype == AACLIP_F32) cross_rows_t<float>(qt, (const float*)x, out, (float*)ws, B, R, Lk, Dk, s);
   else if (x_dtype == AACLIP_F16) cross_rows_t<f16>(qt, (const f16*)x, out, (float*)ws, B, R, Lk, Dk, s);
   else cross_rows_t<bf16>(qt, (const bf16*)x, out, (float*)ws, B, R, Lk, Dk, s);
+}
+
+// ---- cross_rows over SEGMENTS of 16-bit rows, on the matrix cores (aaclip_cross_rows_levels).
+// The visual cross-attention of the IQM layers reads the LayerNorm'ed rows of the four tap levels directly: level k's
+// projections (query_adapters[k], visual_feature_proj, the key / value Linear) are moved onto the query side and
+// behind the probability-weighted row sums, so that per (image, effective query r) the work is
+//     scores_j = qt[b, r, seg] . x_seg[b, j]     over every key row j of every segment (ONE softmax over all of them)
+//     out[b, r, seg] = sum_{j in seg} p_j x_seg[b, j]
+// 16 effective queries x DK = 1024 columns per key row: 64 KFLOP per row, 23 GFLOP per call at B = 64 -- the VALU kernel
+// above needs 0.6 ms for that; as MFMAs it is ~10 us of pipe time and the kernel runs at the rate HBM delivers the rows.
+//   workgroup (256 threads) = (image, segment, slice of the segment's keys); 32-key tiles, double-buffered in LDS by
+//   buffer_load ... lds issued from asm (hipcc would order every LDS read behind a DMA it knows about); LDS image =
+//   plain rows of DK x 2 bytes with the 16-byte chunk index XORed by f(row) = 2 (row & 7) ^ (row >> 3 & 1): the row
+//   reads of the score MFMAs (16 rows, one chunk) and the transposed reads of the P.V MFMAs (4 rows x 2 chunks per 16
+//   lanes) are both conflict-free per 16-lane group.
+//   scores  D[key][q] = X[key][.] . Q[q][.]   16x16x32, A = key rows by ds_read_b128, B = the query fragments (fp16 hi
+//           and lo: two MFMAs per chunk, so the effective queries keep ~22 bits); wave w sums over columns
+//           [w DK/4, (w+1) DK/4), the four partial tiles meet in LDS and every wave adds them in the same order
+//   softmax online, per query = per lane column, identical in every wave (log2 units, fp32)
+//   P.V     D[col][q] = X^T[col][key] . P[key][q]: A by ds_read_b64_tr_b16 (keys 4g..4g+3 of both 16-key blocks on lane
+//           group g -- exactly the keys whose probabilities that lane group's score registers hold), B = P as it
+//           stands, converted to 16 bits; wave w owns output columns [w DK/4, (w+1) DK/4) in 64 / 48 registers.
+// Partial record per (image, segment, slice, query): [DK sums][m][l] like the kernel above; the combine kernel applies
+// ONE maximum and ONE normaliser over all slices of all segments.
+struct CrossSegs { const void* x[4]; };
+AACLIP_DEV int cr_swz(int row) { return ((row & 7) << 1) ^ ((row >> 3) & 1); }
+
+template <typename T, int DK>
+__global__ __launch_bounds__(256) void cross_rows_mfma_kernel(CrossSegs segs, const float* __restrict__ qt,
+                                                              float* __restrict__ part, int R, int rows_per_image,
+                                                              int row0, int Lk, int ldx, int nseg, int slices) {
+  typedef typename Elem<T>::vec8 vec8;
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int RB = DK * 2, TILEB = 32 * RB, QW = DK / 4, NCQ = QW / 32, NT = QW / 16, NI = TILEB / 4096;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILEB + 8192];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, g = lane >> 4;
+  const int seg = __builtin_amdgcn_readfirstlane(blockIdx.x / slices), sl = blockIdx.x - seg * slices, b = blockIdx.y;
+  const int per = (((Lk + slices - 1) / slices) + 31) & ~31;
+  const int j0 = sl * per, j1 = min(Lk, j0 + per);
+  const int dbase = wave * QW;
+  float* prec = part + ((((long)b * nseg + seg) * slices + sl) * 16) * (DK + 2);
+  if (j0 >= j1) {   // an empty slice (workgroup-uniform): a record that the combine kernel skips
+    if (threadIdx.x < 16) { prec[(long)threadIdx.x * (DK + 2) + DK] = -INFINITY; prec[(long)threadIdx.x * (DK + 2) + DK + 1] = 0.f; }
+    return;
+  }
+  // effective queries of this (image, segment): fp32 -> hi + lo fragments of this wave's column quarter (log2 units)
+  vec8 qh[NCQ], ql[NCQ];
+  {
+    const float* qr = qt + ((long)b * R + (c16 < R ? c16 : 0)) * ((long)nseg * DK) + (long)seg * DK + dbase + 8 * g;
+#pragma unroll
+    for (int c = 0; c < NCQ; ++c) {
+      const f32x4 v0 = *(const f32x4*)(qr + 32 * c), v1 = *(const f32x4*)(qr + 32 * c + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = (e < 4 ? v0[e] : v1[e - 4]) * 1.4426950408889634f;
+        if (c16 >= R) v = 0.f;
+        const T h = (T)v;
+        qh[c][e] = h;
+        ql[c][e] = (T)(v - (float)h);
+      }
+    }
+  }
+  // DMA: descriptor over this segment's rows of image b, per-lane offsets of the wave's NI slots of a tile
+  const unsigned long long ubase = (unsigned long long)((const T*)segs.x[seg] + ((long)b * rows_per_image + row0) * ldx);
+  u32x4 rs;
+  rs[0] = __builtin_amdgcn_readfirstlane((unsigned)ubase);
+  rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(ubase >> 32)) & 0xFFFFu;
+  rs[2] = 0x7FFFFFF0u;
+  rs[3] = 0x00020000u;
+  const int ldb = ldx * 2;
+  int dvo[NI], drow[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int o = (wave * NI + j) * 1024 + lane * 16;
+    const int row = o / RB, ch = (o - row * RB) >> 4;
+    drow[j] = row;
+    dvo[j] = row * ldb + ((ch ^ cr_swz(row)) << 4);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + wave * (NI * 1024);
+  auto dma16 = [&](unsigned lds_addr, int voff_b, int soff_b) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff_b), "s"(rs), "s"(soff_b) : "memory");
+  };
+  auto stage = [&](int st, int jt) {
+    const unsigned dst = lds0 + st * TILEB;
+    const int so = __builtin_amdgcn_readfirstlane(jt * ldb);
+    if (jt + 32 <= j1) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) dma16(dst + j * 1024, dvo[j], so);
+    } else {   // last tile: rows past the slice re-read its last row (finite data; their scores are masked)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        int over = jt + drow[j] - (j1 - 1);
+        over = over > 0 ? over : 0;
+        dma16(dst + j * 1024, dvo[j] - over * ldb, so);
+      }
+    }
+  };
+  // LDS read offsets: score A operand (key row c16 of block kb, this wave's chunk c, lane group's 16 bytes) and the
+  // transposed P.V operand (lane 4q+p of a group: key row 4g+q, columns 4p..4p+3 of the 16-column tile)
+  const int sw_s[2] = {cr_swz(c16), cr_swz(16 + c16)};
+  const int trow = 4 * g + (c16 >> 2), sw_t[2] = {cr_swz(trow), cr_swz(16 + trow)};
+  const int tcol = (c16 & 3) >> 1, tb8 = (c16 & 1) * 8;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  f32x4* red = (f32x4*)(smem + 2 * TILEB);
+  const int ntiles = (j1 - j0 + 31) >> 5;
+  stage(0, j0);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // tile t has landed for every wave; buffer (t+1)&1 is free
+    if (t + 1 < ntiles) stage((t + 1) & 1, j0 + (t + 1) * 32);
+    const char* sb = smem + (t & 1) * TILEB;
+    f32x4 sp[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      sp[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const char* rowp = sb + (kb * 16 + c16) * RB;
+#pragma unroll
+      for (int c = 0; c < NCQ; ++c) {
+        const int ch = ((dbase + 32 * c) >> 3) + g;
+        const vec8 a = *(const vec8*)(rowp + ((ch ^ sw_s[kb]) << 4));
+        sp[kb] = Mma16<T>::mma(a, qh[c], sp[kb]);
+        sp[kb] = Mma16<T>::mma(a, ql[c], sp[kb]);
+      }
+      red[(wave * 2 + kb) * 64 + lane] = sp[kb];
+    }
+    __syncthreads();
+    float s[2][4];
+    const int jt = j0 + t * 32;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 v = red[kb * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v = v + red[(w * 2 + kb) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[kb][e] = (jt + kb * 16 + 4 * g + e < j1) ? v[e] : -INFINITY;
+    }
+    float tm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    const float mn = fmaxf(m, tm);                       // finite: every tile has at least one key of the slice
+    const float f = __builtin_amdgcn_exp2f(m - mn);      // 2^-inf = 0 on the first tile
+    float ps = 0.f;
+    vec8 pb;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pj = __builtin_amdgcn_exp2f(s[kb][e] - mn);
+        ps += pj;
+        pb[4 * kb + e] = (T)pj;
+      }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * f + ps;
+    m = mn;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cb = ((dbase + 16 * nt) >> 3) + tcol;
+      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(sb + trow * RB + ((cb ^ sw_t[0]) << 4) + tb8));
+      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(sb + (16 + trow) * RB + ((cb ^ sw_t[1]) << 4) + tb8));
+      typedef short i16x8 __attribute__((ext_vector_type(8)));
+      const i16x8 a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc[nt] = acc[nt] * f;
+      acc[nt] = Mma16<T>::mma(__builtin_bit_cast(vec8, a8), pb, acc[nt]);
+    }
+  }
+  if (c16 < R) {
+    float* pr = prec + (long)c16 * (DK + 2);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *(f32x4*)(pr + dbase + 16 * nt + 4 * g) = acc[nt];
+    if (wave == 0 && g == 0) { pr[DK] = m; pr[DK + 1] = l; }
+  }
+}
+// one maximum and one normaliser over all slices of all segments; out [B*R, nseg*Dk]
+__global__ __launch_bounds__(256) void cross_rows_levels_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                        int R, int Dk, int nseg, int slices) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  const int n = nseg * slices;
+  const float* base = part + ((long)b * n * 16 + r) * (Dk + 2);
+  const long rec = 16L * (Dk + 2);
+  float m = -INFINITY;
+  for (int s = 0; s < n; ++s) m = fmaxf(m, base[s * rec + Dk]);
+  float l = 0.f;
+  for (int s = 0; s < n; ++s)
+    if (base[s * rec + Dk + 1] > 0.f) l += base[s * rec + Dk + 1] * exp2f(base[s * rec + Dk] - m);
+  const float inv = 1.0f / l;
+  for (int i = threadIdx.x; i < nseg * Dk; i += 256) {
+    const int sg = i / Dk, d = i - sg * Dk;
+    float a = 0.f;
+    for (int s = sg * slices; s < (sg + 1) * slices; ++s)
+      if (base[s * rec + Dk + 1] > 0.f) a += base[s * rec + d] * exp2f(base[s * rec + Dk] - m);
+    out[((long)b * R + r) * ((long)nseg * Dk) + i] = a * inv;
+  }
+}
+int cross_rows_levels_slices(int B, int nseg, int Lk) {
+  int s = (512 + B * nseg - 1) / (B * nseg);          // >= 2 workgroups per CU's worth of slices at small batches
+  const int most = (Lk + 63) / 64;                    // >= 64 keys per slice
+  s = s < most ? s : most;
+  s = s < 1 ? 1 : (s > 32 ? 32 : s);
+  return s;
+}
+const char* cross_rows_levels_check(int x_dtype, int R, int nseg, int Lk, int Dk, long ldx) {
+  if (x_dtype != AACLIP_F16 && x_dtype != AACLIP_BF16) return "cross_rows_levels: rows must be fp16 or bf16";
+  if (R < 1 || R > 16) return "cross_rows_levels: 1..16 effective queries per image";
+  if (nseg < 1 || nseg > 4) return "cross_rows_levels: 1..4 segments";
+  if (Lk < 1) return "cross_rows_levels: no keys";
+  if (Dk != 768 && Dk != 1024) return "cross_rows_levels: row width must be 768 or 1024";
+  if (ldx < Dk || (ldx & 7)) return "cross_rows_levels: row stride must be >= the width and a multiple of 8 elements";
+  return nullptr;
+}
+size_t cross_rows_levels_ws_bytes(int B, int nseg, int Lk, int Dk) {
+  return (size_t)B * nseg * cross_rows_levels_slices(B, nseg, Lk) * 16 * (Dk + 2) * 4;
+}
+void launch_cross_rows_levels(int x_dtype, const float* qt, const void* const* x, int nseg, float* out, void* ws, int B,
+                              int R, int rows_per_image, int row0, int Lk, int Dk, long ldx, hipStream_t s) {
+  const int slices = cross_rows_levels_slices(B, nseg, Lk);
+  CrossSegs segs;
+  for (int i = 0; i < 4; ++i) segs.x[i] = x[i < nseg ? i : 0];
+  dim3 g(nseg * slices, B), blk(256);
+  float* part = (float*)ws;
+#define CRL(T, DKV) hipLaunchKernelGGL((cross_rows_mfma_kernel<T, DKV>), g, blk, 0, s, segs, qt, part, R, rows_per_image, row0, Lk, (int)ldx, nseg, slices)
+  if (x_dtype == AACLIP_F16) { if (Dk == 1024) CRL(f16, 1024); else CRL(f16, 768); }
+  else { if (Dk == 1024) CRL(bf16, 1024); else CRL(bf16, 768); }
+#undef CRL
+  hipLaunchKernelGGL(cross_rows_levels_combine_kernel, dim3(R, B), dim3(256), 0, s, part, out, R, Dk, nseg, slices);
 }
 
 // head_expand: q [rows, D] fp32 -> qm [rows * H, D] of T, row (r, h) = q[r] * scale inside head h's column slice, zero

@@ -112,6 +112,10 @@ const char* cross_rows_check(int R, int Lk, int Dk);
 size_t cross_rows_ws_bytes(int B, int R, int Lk, int Dk);
 void launch_cross_rows(int x_dtype, const float* qt, const void* x, float* out, void* ws, int B, int R, int Lk, int Dk,
                        hipStream_t s);
+const char* cross_rows_levels_check(int x_dtype, int R, int nseg, int Lk, int Dk, long ldx);
+size_t cross_rows_levels_ws_bytes(int B, int nseg, int Lk, int Dk);
+void launch_cross_rows_levels(int x_dtype, const float* qt, const void* const* x, int nseg, float* out, void* ws, int B,
+                              int R, int rows_per_image, int row0, int Lk, int Dk, long ldx, hipStream_t s);
 void launch_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, hipStream_t s);
 void launch_head_diag(const float* full, float* ctx, long rows, int H, int D, hipStream_t s);
 void launch_residual_layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, long rows,

@@ -101,7 +101,14 @@ class AdaptedCLIP(nn.Module):
         icode = engine.plain_code(code)     # the IQM side branch has no split-fp16 kernels: exact fp32 under fp16x2
         dt = engine.torch_dtype(icode)
         P = L - 1
-        vis_cat = torch.empty(B, n_levels * P, self.iqm_hidden_size, dtype=dt, device=xs.device) if iqm_on else None
+        # 16-bit towers without the LeakyReLU in query_adapters: every step from the LayerNorm'ed tap rows to the keys and
+        # values of the IQM cross-attention is linear, so the branch reads those rows as they are (_iqm_levels); otherwise
+        # the levels are projected and concatenated like the reference does (_iqm_project_level)
+        fold_levels = (iqm_on and not self.relu and code in (engine.F16, engine.BF16, engine.F16X2)
+                       and 2 * self.iqm.num_attention_heads <= 16 and xs.shape[-1] in (768, 1024))
+        ln_rows = []
+        vis_cat = (torch.empty(B, n_levels * P, self.iqm_hidden_size, dtype=dt, device=xs.device)
+                   if iqm_on and not fold_levels else None)
         # the whole tower with its adapters in ONE library call; the stream after every level stays in its own buffer
         # (no copies: the block behind a tap continues in a fresh one), the heads read them afterwards
         aws = [adapters[i].weight if i < self.image_adapt_until else None for i in range(len(blocks))]
@@ -111,17 +118,35 @@ class AdaptedCLIP(nn.Module):
         det_token = None
         for k, tap in enumerate(taps):
             last = k == n_levels - 1
-            seg, det = engine.tap_head(
+            res = engine.tap_head(
                 tap, v.ln_post, self.image_adapter["seg_proj"][k].weight, self.relu, B, L, code,
-                det_weight=self.image_adapter["det_proj"].weight if last else None)
-            seg_tokens.append(seg)
+                det_weight=self.image_adapter["det_proj"].weight if last else None, keep_rows=fold_levels)
+            seg_tokens.append(res[0])
             if last:
-                det_token = det
-            if iqm_on:
+                det_token = res[1]
+            if fold_levels:
+                ln_rows.append(res[2])
+            elif iqm_on:
                 self._iqm_project_level(tap, k, vis_cat, B, L, icode)
         if not iqm_on:
             return seg_tokens, det_token, None
-        return seg_tokens, det_token, self._iqm_branch(xs, vis_cat, text_embeddings, B, L, icode)
+        levels = self._iqm_levels(ln_rows, L, icode) if fold_levels else None
+        return seg_tokens, det_token, self._iqm_branch(xs, vis_cat, text_embeddings, B, L, icode, levels)
+
+    # -- the folded form of reference model/adapter.py:205-211: level k's rows stay ln_post(tap k) [B*L, D] (what the tap
+    #    head computed anyway); query_adapters[k] enters the cross-attention as two concatenated weights
+    def _iqm_levels(self, ln_rows, L, code):
+        ws = [qa.weight for qa in self.query_adapters]
+        key = (code,) + tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
+        if getattr(self, "_qa_cat_key", None) != key:
+            dt = engine.torch_dtype(code)
+            with torch.no_grad():
+                w_in = torch.cat([w.detach().float().t() for w in ws], 0).to(dt).contiguous()     # [levels*D, h]
+                w_out = torch.cat([w.detach().float() for w in ws], 1).to(dt).contiguous()        # [h, levels*D]
+            self._qa_cat, self._qa_cat_key = (w_in, w_out), key
+        w_in, w_out = self._qa_cat
+        return {"rows": ln_rows, "rows_per_image": L, "row0": 1, "keys": L - 1, "width": ws[0].shape[1],
+                "w_in": w_in, "w_out": w_out}
 
     # -- reference model/adapter.py:205-208: query_adapters[k](ln_post(tap k)) for the patch rows, written into the
     #    slice of the concatenated visual features (torch.cat over dim 1, :210-211) that level k owns
@@ -144,7 +169,7 @@ class AdaptedCLIP(nn.Module):
         engine.drop_cls_rows(tmp, vis_cat, B, L, k * (L - 1), code)
 
     # -- reference model/adapter.py:186-269
-    def _iqm_branch(self, xs, vis_cat, text_embeddings, B, L, code):
+    def _iqm_branch(self, xs, vis_cat, text_embeddings, B, L, code, levels=None):
         dt = engine.torch_dtype(code)
         h = self.iqm_hidden_size
         dev = xs.device
@@ -170,7 +195,7 @@ class AdaptedCLIP(nn.Module):
         txt = engine.linear_smallk(te, tp.weight, tp.bias, code)
         out = self.iqm(query_embeds=query, query_length=2, encoder_hidden_states=vis_cat,
                        text_encoder_hidden_states=txt.view(B, te.shape[1], tp.weight.shape[0]), code=code,
-                       encoder_proj=(vp.weight, vp.bias))
+                       encoder_proj=(vp.weight, vp.bias), encoder_levels=levels)
         hfin = engine.residual_layernorm(out.last_hidden_state.reshape(B * 2, h), None, self.iqm_layer_norm,
                                          self.iqm_layer_norm.eps)                             # :265-266
         return IQMOutput(hfin.view(B, 2, h), pooler_output=out.last_hidden_state.reshape(B, 2, h)[:, 0, :])

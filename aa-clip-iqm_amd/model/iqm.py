@@ -104,7 +104,7 @@ class IQM(nn.Module):
 
     # ---- one IQM_Attention: q from h [B*nq, D] (fp32), k/v = Linear(enc) where enc is [B*Lk, Dk] in the compute dtype
     def _attend(self, att: _Attention, h: torch.Tensor, enc: Optional[torch.Tensor], B: int, nq: int, Lk: int,
-                code: int, enc_proj=None) -> torch.Tensor:
+                code: int, enc_proj=None, enc_levels=None) -> torch.Tensor:
         dt = engine.torch_dtype(code)
         D = self.hidden_size
         hq = h.to(dt)                                      # [B*nq, D]: 2 rows per image
@@ -112,6 +112,34 @@ class IQM(nn.Module):
         engine.gemm(code, EPI_ACT_F32, hq, engine.CACHE.get(att.attention.query.weight, code),
                     engine._f32c(att.attention.query.bias), q)
         H = self.num_attention_heads
+        if enc_levels is not None:
+            # the rows are level s's LayerNorm'ed tap rows t, enc = P (W_qa[s] t) + b_p (query_adapters, torch.cat,
+            # visual_feature_proj: reference model/adapter.py:205-221), every step linear: all of it moves to the query
+            # side and behind the weighted sums (include/aaclip.h, aaclip_cross_rows_levels) -- no per-row product at all
+            lv = enc_levels
+            pw, pb = enc_proj
+            qm = engine.head_expand(q, H, 1.0 / math.sqrt(D // H), code)                         # [B*nq*H, D]
+            kin = att.attention.key.weight.shape[1]
+            qt = torch.empty(B * nq * H, kin, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, qm, engine.CACHE.get(att.attention.key.weight, code, "transpose"), None, qt)
+            qx = torch.empty(B * nq * H, pw.shape[1], dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, qt.to(dt), engine.CACHE.get(pw, code, "transpose"), None, qx)
+            nseg, Dk = len(lv["rows"]), lv["width"]
+            u = torch.empty(B * nq * H, nseg * Dk, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, qx.to(dt), lv["w_in"], None, u)        # u[., s] = W_qa[s]^T qx
+            tbar = engine.cross_rows_levels(u, lv["rows"], B, nq * H, lv["rows_per_image"], lv["row0"], lv["keys"], Dk)
+            xbar = torch.empty(B * nq * H, pw.shape[1], dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, tbar.to(dt), lv["w_out"], None, xbar)  # sum_s W_qa[s] tbar[., s]
+            ebar = torch.empty(B * nq * H, kin, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, xbar.to(dt), engine.CACHE.get(pw, code), engine._f32c(pb), ebar)
+            full = torch.empty(B * nq * H, D, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, ebar.to(dt), engine.CACHE.get(att.attention.value.weight, code),
+                        engine._f32c(att.attention.value.bias), full)
+            ctx = engine.head_diag(full, H)
+            dense = torch.empty(B * nq, D, dtype=torch.float32, device=h.device)
+            engine.gemm(code, EPI_ACT_F32, ctx.to(dt), engine.CACHE.get(att.output.dense.weight, code),
+                        engine._f32c(att.output.dense.bias), dense)
+            return engine.residual_layernorm(dense, h, att.output.LayerNorm, self.eps)
         if enc is not None and (nq * H) % 4 == 0 and nq * H <= 16 and enc.shape[-1] in (256, 512, 768, 1024):
             # cross-attention over MANY rows for a handful of queries: W_k moves to the query side and W_v behind the
             # probability-weighted sum of the raw rows (include/aaclip.h, aaclip_cross_rows): the reference's key /
@@ -157,26 +185,35 @@ class IQM(nn.Module):
     def forward(self, query_embeds: torch.Tensor, query_length: Optional[int] = None,
                 encoder_hidden_states: Optional[torch.Tensor] = None,
                 text_encoder_hidden_states: Optional[torch.Tensor] = None, code: Optional[int] = None,
-                encoder_proj=None, **_unused):
+                encoder_proj=None, encoder_levels=None, **_unused):
         """query_embeds fp32 [B, nq, D]; encoder_hidden_states [B, Lv, D] and text_encoder_hidden_states [B, Lt, D] in
         the compute dtype (or fp32) -> IQMOutput.  reference model/iqm.py:572-673 with all masks zero.
         encoder_proj = (weight, bias): encoder_hidden_states are the rows BEFORE that Linear; it is folded into the
-        cross-attention (see _attend) instead of being applied to every row."""
+        cross-attention (see _attend) instead of being applied to every row.
+        encoder_levels (instead of encoder_hidden_states; AdaptedCLIP._iqm_levels builds it): the LayerNorm'ed rows of
+        the tap levels themselves plus the concatenated query_adapters weights -- the level projections fold too."""
         engine.require_gpu(query_embeds, "IQM")
         if code is None:
             code = engine.dtype_code(getattr(self, "precision", "fp32"))
         code = engine.plain_code(code)          # no split-fp16 kernels on this side branch: exact fp32 under fp16x2
         dt = engine.torch_dtype(code)
         B, nq, D = query_embeds.shape
-        if encoder_hidden_states is None or text_encoder_hidden_states is None:
+        if (encoder_hidden_states is None and encoder_levels is None) or text_encoder_hidden_states is None:
             raise ValueError("encoder_hidden_states must be given for cross-attention layers")     # iqm.py:289
-        vis = encoder_hidden_states.to(dt).reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
+        if encoder_levels is not None:
+            if encoder_proj is None or (nq * self.num_attention_heads) > 16:
+                raise ValueError("encoder_levels needs encoder_proj and at most 16 queries x heads per image")
+            vis, Lv = None, encoder_levels["keys"] * len(encoder_levels["rows"])
+        else:
+            vis = encoder_hidden_states.to(dt).reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
+            Lv = encoder_hidden_states.shape[1]
         txt = text_encoder_hidden_states.to(dt).reshape(-1, text_encoder_hidden_states.shape[-1]).contiguous()
-        Lv, Lt = encoder_hidden_states.shape[1], text_encoder_hidden_states.shape[1]
+        Lt = text_encoder_hidden_states.shape[1]
         h = engine.residual_layernorm(engine._f32c(query_embeds).reshape(B * nq, D), None, self.layernorm, self.eps)
         for layer in self.encoder.layer:
             a = self._attend(layer.attention, h, None, B, nq, nq, code)
-            c = self._attend(layer.crossattention, a, vis, B, nq, Lv, code, enc_proj=encoder_proj)
+            c = self._attend(layer.crossattention, a, vis, B, nq, Lv, code, enc_proj=encoder_proj,
+                             enc_levels=encoder_levels)
             t = self._attend(layer.text_crossattention, c, txt, B, nq, Lt, code)
             mix = engine.combine3(a, c, t, 0.4, 0.3, 0.3)                                            # iqm.py:311-315
             inter = torch.empty(B * nq, layer.intermediate_query.dense.weight.shape[0], dtype=dt, device=h.device)

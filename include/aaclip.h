@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define AACLIP_ABI_VERSION 4
+#define AACLIP_ABI_VERSION 5   /* 5: + aaclip_tap_head_keep_rows, aaclip_cross_rows_levels (additions only) */
 
 enum { AACLIP_F32 = 0, AACLIP_F16 = 1, AACLIP_BF16 = 2, AACLIP_F16X2 = 3 };
 enum { AACLIP_ACT_NONE = 0, AACLIP_ACT_LEAKY = 1, AACLIP_ACT_RELU = 2 };
@@ -168,6 +168,14 @@ int aaclip_tap_head(const float* x, const float* ln_post_w, const float* ln_post
                     float* seg_out, const void* det_w, float* det_out, int B, int L, int D, int E, int dtype, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* The same, and the LayerNorm'ed rows ln_post(x) [B*L, D] are left in ln_rows_out in the layout of `dtype` (fp32 /
+ * fp16 / bf16 rows of D elements; AACLIP_F16X2: split8 rows of 4 D bytes whose first 2 D bytes are the fp16 values):
+ * the IQM branch reads exactly these rows again (reference model/adapter.py:205-208 applies ln_post to every tap a
+ * second time), so they are computed once. */
+int aaclip_tap_head_keep_rows(const float* x, const float* ln_post_w, const float* ln_post_b, const void* proj_w, int act,
+                              float* seg_out, const void* det_w, float* det_out, void* ln_rows_out, int B, int L, int D,
+                              int E, int dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* Detection head alone (reference model/adapter.py:183-184). */
 int aaclip_det_head(const float* x, const float* ln_post_w, const float* ln_post_b, const void* det_w, int act,
                     float* det_out, int B, int L, int D, int E, int dtype, void* ws, size_t ws_bytes, void* stream);
@@ -276,6 +284,21 @@ int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight,
 size_t aaclip_cross_rows_workspace_bytes(int B, int R, int Lk, int Dk);
 int aaclip_cross_rows(int x_dtype, const float* qt, const void* x, float* out, int B, int R, int Lk, int Dk, void* ws,
                       size_t ws_bytes, void* stream);
+/* The same over up to 4 SEGMENTS of 16-bit rows that share one softmax, on the matrix cores: segment s has its own row
+ * buffer x[s] (image b's keys are rows b * rows_per_image + row0 + j, j < Lk, of ldx elements each, the first Dk of
+ * which are read) and its own effective queries: qt, out [B, R, nseg, Dk] fp32,
+ *   p = softmax over all (s, j) of qt[b, r, s] . x[s][b, j];   out[b, r, s] = sum_j p_(s, j) x[s][b, j].
+ * This is the visual cross-attention of IQM on the LayerNorm'ed tap rows themselves (aaclip_tap_head_keep_rows; row0 = 1
+ * skips the CLS row): with query_adapters[s] (reference model/adapter.py:205-208, a Linear without bias when relu is
+ * off), torch.cat over the levels (:210-211), visual_feature_proj (:213-221) and the key / value Linear all linear in
+ * the rows, each moves to the query side (qt[., s] = W_qa[s]^T P^T W_k[h]^T q_h / sqrt(d)) and behind the weighted
+ * sums (sum_s W_qa[s] out[., s], then P, W_v) as [R, .] products through aaclip_gemm -- no per-row projection is left.
+ * x_dtype AACLIP_F16 or AACLIP_BF16 (for the fp16 halves of split8 rows pass AACLIP_F16 and ldx = 2 Dk), R <= 16,
+ * Dk 768 or 1024, ldx a multiple of 8. */
+size_t aaclip_cross_rows_levels_workspace_bytes(int B, int nseg, int Lk, int Dk);
+int aaclip_cross_rows_levels(int x_dtype, const float* qt, const void* const* x, int nseg, float* out, int B, int R,
+                             int rows_per_image, int row0, int Lk, int Dk, long ldx, void* ws, size_t ws_bytes,
+                             void* stream);
 int aaclip_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, void* stream);
 int aaclip_head_diag(const float* full, float* ctx, long rows, int H, int D, void* stream);
 int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,

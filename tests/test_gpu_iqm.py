@@ -96,6 +96,43 @@ def test_cross_rows_equals_projected_cross_attention(dev, code, shape):
     assert lib.aaclip_cross_rows(code, 1, 1, 1, 2, 16, 100, 768, 1, 16, None) < 0              # workspace too small
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "bf16", "split8"])
+@pytest.mark.parametrize("shape", [(3, 16, 4, 1370, 1, 1369, 1024), (2, 16, 1, 768, 0, 768, 768), (2, 8, 2, 300, 1, 299, 1024),
+                                   (1, 4, 3, 40, 3, 33, 768), (5, 12, 4, 131, 1, 130, 1024), (70, 16, 1, 97, 0, 97, 768)])
+def test_cross_rows_levels_vs_fp64(dev, fmt, shape):
+    """aaclip_cross_rows_levels (the MFMA kernel over segments of 16-bit rows that share one softmax) against fp64 on the
+    same 16-bit row values: ragged key counts (not multiples of the 32-key tile), skipped leading rows (row0), 1-4
+    segments, fewer than 16 effective queries, rows read out of split8 records (stride 2 Dk)."""
+    B, R, nseg, rpi, row0, Lk, Dk = shape
+    tdt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    qt = synth.randn("crl.q", (B * R, nseg * Dk), 2.5 * Dk ** -0.5, 1)
+    qt[:, ::7] *= 3.0
+    xs = [synth.randn(f"crl.x{s}", (B * rpi, Dk), 1.0 + 0.5 * s, 2 + s, 0.1 * s).to(tdt) for s in range(nseg)]
+    if fmt == "split8":
+        levels = []
+        for x in xs:
+            rec = torch.full((B * rpi, 4 * Dk), 0x7F, dtype=torch.uint8)       # NaN bytes wherever the kernel must not look
+            rec[:, :2 * Dk] = x.contiguous().view(torch.uint8).view(B * rpi, 2 * Dk)
+            levels.append(rec.to(dev))
+    else:
+        levels = [x.to(dev) for x in xs]
+    out = engine.cross_rows_levels(qt.to(dev), levels, B, R, rpi, row0, Lk, Dk)
+    assert out.shape == (B * R, nseg * Dk)
+    q64 = qt.double().view(B, R, nseg, Dk)
+    keys = [x.double().view(B, rpi, Dk)[:, row0:row0 + Lk] for x in xs]
+    sc = torch.cat([torch.einsum("brd,bjd->brj", q64[:, :, s], keys[s]) for s in range(nseg)], -1)
+    p = torch.softmax(sc, -1)
+    ref = torch.stack([torch.einsum("brj,bjd->brd", p[:, :, s * Lk:(s + 1) * Lk], keys[s]) for s in range(nseg)], 2)
+    # the probabilities enter the second product in 16 bits (2^-12 / 2^-9 relative, independent per key)
+    tol = 6e-4 if fmt != "bf16" else 5e-3
+    close(out, ref.reshape(B * R, nseg * Dk), tol * float(ref.abs().max()), 0.0, f"cross_rows_levels {fmt} {shape}")
+    lib = _lib.load()
+    assert lib.aaclip_cross_rows_levels(F32, 1, 1, 1, 1, 1, 4, 10, 0, 10, 768, 768, 1, 1 << 30, None) < 0     # fp32 rows
+    assert lib.aaclip_cross_rows_levels(F16, 1, 1, 1, 1, 1, 4, 10, 1, 10, 768, 768, 1, 1 << 30, None) < 0     # keys past the image
+    assert lib.aaclip_cross_rows_levels(F16, 1, 1, 1, 1, 1, 17, 10, 0, 10, 768, 768, 1, 1 << 30, None) < 0    # R = 17
+    assert lib.aaclip_cross_rows_levels(F16, 1, 1, 1, 1, 1, 4, 10, 0, 10, 512, 512, 1, 1 << 30, None) < 0     # width
+
+
 def test_residual_layernorm_combine_smallk_dropcls(dev):
     lib = _lib.load()
     a, b = synth.randn("iq.a", (10, 768), 2.0, 1, 0.5), synth.randn("iq.b", (10, 768), 1.0, 2)

@@ -19,8 +19,9 @@ model = model.to(dev).eval()
 gen = torch.Generator(device=dev).manual_seed(1)
 images = torch.randn(64, 3, 518, 518, generator=gen, device=dev)
 te = torch.nn.functional.normalize(torch.randn(64, 768, 2, generator=gen, device=dev), dim=1)
+iqm = not (len(sys.argv) > 2 and sys.argv[2] == "noiqm")     # "noiqm": the same forward without the side branch
 with torch.no_grad():
     for _ in range(3):
-        model(images, text_embeddings=te)
+        model(images, text_embeddings=te if iqm else None)
 torch.cuda.synchronize()
 print("done")
