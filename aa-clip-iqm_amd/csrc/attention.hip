@@ -251,9 +251,20 @@ __global__ __launch_bounds__(256, 3) void attn16_kernel(const T* __restrict__ qk
 // Stage image: [Kh 8K][Vh 8K][Kl 8K], two stages = 48 KiB: three workgroups per CU.
 // VL = true keeps the fifth product (stage image + [Vl 8K], two workgroups per CU): short sequences (the text tower's
 // L = 77, the V-V path over the batch axis) have too few keys per row for the averaging argument, and cost nothing.
-template <bool LOG2Q, bool VL>
+// QK8 = true (the block path at L >= 512): the two correction products run on the block-scaled e4m3 MFMA like the
+// GEMMs' (v_mfma_scale_f32_32x32x64_f8f6f4: head dim 64 = ONE instruction per 32 keys x 32 queries, 64 pipe cycles
+// where the four fp16 MFMAs of a correction product take 128).  Rows then are
+//   [q k v hi: 3D fp16][q: per head [lo8 64 B | hi8 64 B]][k: the same]        10 D bytes, stride 5D halves
+// (lo8 = e4m3((x - hi) 2^10), hi8 = e4m3(x), written by the QKV epilogue, GemmParams::out_qk8): the 128-byte e4m3 record
+// of a (row, head) has the geometry of a 64-column fp16 row, so the K8 tile is staged by the same DMA pattern as Kl was
+// and tools/mfma_f8_32_probe.hip's operand map (lane (row, h) holds K bytes [16h, 16h+16) and [32+16h, 32+16h+16)) makes
+// the fragments of the fp16 row read -- chunks h, 2+h | 4+h, 6+h -- exactly the Kl8 and Kh8 operands; likewise the four
+// 16-byte loads that fetched ql now fetch Ql8 | Qh8.  Per 64-key tile: 768 pipe cycles instead of 1024.
+template <bool LOG2Q, bool VL, bool QK8 = false>
 __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __restrict__ qkv, f16* __restrict__ ctx, int L, int H,
                                                          int causal, int nqt, int total, int per_xcd, bool hi8) {
+  static_assert(!(QK8 && VL), "the e4m3 correction form exists for the long-row kernel only");
+  fp8_saturate_mode();   // the context rows are converted with split8x4_sat
   typedef f16x8 vec8;
   typedef f16x4 vec4;
   typedef short i16x8 __attribute__((ext_vector_type(8)));
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
   const int qt = lin % nqt, bh = lin / nqt;
   const int head = bh % H, b = bh / H;
   const int D = H * 64;
-  const long ld = 6L * D;      // split row: [q k v hi | q k v lo]
+  const long ld = QK8 ? 5L * D : 6L * D;      // split row: [q k v hi | q k v lo], or [q k v hi | q8 | k8] (see above)
   const int LO = 3 * D;
   const f16* base = qkv + (long)b * L * ld + head * 64;
   const int q0 = qt * 128 + wave * 32;
@@ -342,6 +353,25 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[sub][e] = LOG2Q ? -m2 : 0.f;
+      if constexpr (QK8) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x8 __attribute__((ext_vector_type(8)));
+        i32x4 k8[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) k8[ks] = *(const i32x4*)(sb + 16384 + koff[ks] + sub * 4096);
+        const i32x8 kl8 = __builtin_shufflevector(k8[0], k8[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 kh8 = __builtin_shufflevector(k8[2], k8[3], 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 ql8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, ql[0]), __builtin_bit_cast(i32x4, ql[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 qh8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, ql[2]), __builtin_bit_cast(i32x4, ql[3]), 0, 1, 2, 3, 4, 5, 6, 7);
+        constexpr int S_LO = (127 - SPLIT8_ACT_LO_EXP) * 0x01010101, S_ONE = 127 * 0x01010101;   // e8m0 block scales
+        s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kl8, qh8, s[sub], 0, 0, 0, S_LO, 0, S_ONE);
+        s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kh8, ql8, s[sub], 0, 0, 0, S_ONE, 0, S_LO);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const vec8 ah = *(const vec8*)(sb + koff[ks] + sub * 4096);
+          s[sub] = Elem<f16>::mma32(ah, qh[ks], s[sub]);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const vec8 ah = *(const vec8*)(sb + koff[ks] + sub * 4096);
@@ -349,6 +379,7 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
         s[sub] = Elem<f16>::mma32(al, qh[ks], s[sub]);
         s[sub] = Elem<f16>::mma32(ah, ql[ks], s[sub]);
         s[sub] = Elem<f16>::mma32(ah, qh[ks], s[sub]);
+      }
       }
       if (!LOG2Q) {
 #pragma unroll
@@ -447,7 +478,7 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
                              o[db][4 * gi + 3] * inv};
         vec4 vh;
         uint32_t l8, h8;
-        split8x4(vv, vh, l8, h8);
+        split8x4_sat(vv, vh, l8, h8);
         const int col = db * 32 + 8 * gi + 4 * h;
         *(vec4*)(dst + col) = vh;
         uint8_t* p8 = (uint8_t*)(dst - head * 64 + D) + head * 64;   // e4m3 planes of this row: lo8 at 2D bytes, hi8 at 3D
@@ -1978,15 +2009,18 @@ bool set_attn_variant(int v) {
   return ok;
 }
 
+bool attention_qk8_applicable(int L, int causal) { return L >= 512 && !causal; }
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
-                      hipStream_t s, bool hi8) {
+                      hipStream_t s, bool hi8, bool qk8) {
   if (dtype == AACLIP_F16X2) {   // split fp16 rows in, split fp16 rows out
     const int nqt = (L + 127) / 128;
     const long totl = (long)nqt * H * B;
     const int per_xcd = (int)((totl + 7) / 8), tot = (int)totl;
     dim3 g((unsigned)(per_xcd * 8));
 #define ATTN_LAUNCH_S(LQ, VLO) hipLaunchKernelGGL((attn16s_kernel<LQ, VLO>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd, hi8)
-    if (L >= 512) {   // long rows: v's lo half is not read (see attn16s_kernel)
+    if (qk8) {        // block path, long rows: [q k v hi | q8 | k8] records, correction products on the e4m3 MFMA
+      hipLaunchKernelGGL((attn16s_kernel<true, false, true>), g, dim3(256), 0, s, (const f16*)qkv, (f16*)ctx, L, H, causal, nqt, tot, per_xcd, hi8);
+    } else if (L >= 512) {   // long rows: v's lo half is not read (see attn16s_kernel)
       if (log2q) ATTN_LAUNCH_S(true, false); else ATTN_LAUNCH_S(false, false);
     } else {
       if (log2q) ATTN_LAUNCH_S(true, true); else ATTN_LAUNCH_S(false, true);

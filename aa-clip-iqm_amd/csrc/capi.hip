@@ -431,8 +431,16 @@ static int block_impl(const float* x_in, float* x, const aaclip_block_weights* w
       ProfScope ps(0, s);
       launch_layernorm(dtype, x_in, w->ln1_w, w->ln1_b, narrow, rows, D, 1e-5f, s, !(ex & AACLIP_EXACT16_QKV));
     }
+    // split fp16, long rows, 256-tile QKV kernel: q and k leave the epilogue as fp16 + e4m3 records and the attention
+    // kernel runs its two correction products on the e4m3 MFMA (attention.hip, QK8)
+    bool qk8 = false;
+    if (dtype == AACLIP_F16X2 && log2q && attention_qk8_applicable(L, attn_mode == AACLIP_ATTN_CAUSAL)) {
+      p.ldc = 5 * D; p.out_qk8 = 2 * D;
+      qk8 = gemm_split_routes_to_256t(p);
+      if (!qk8) { p.ldc = sw * 3 * D; p.out_qk8 = 0; }
+    }
     { ProfScope ps(1, s); launch_gemm(dtype, EPI_BIAS, p, s); }
-    { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s, !(ex & AACLIP_EXACT16_OUT)); }
+    { ProfScope ps(2, s); launch_attention(dtype, big, narrow, B, L, H, attn_mode == AACLIP_ATTN_CAUSAL, log2q, s, !(ex & AACLIP_EXACT16_OUT), qk8); }
   }
   memset(&p, 0, sizeof(p));
   p.A = ctx; p.lda = sw * D; p.W = w->out_w; p.M = M; p.N = D; p.K = D; p.bias = w->out_b; p.out = x; p.ldc = D;

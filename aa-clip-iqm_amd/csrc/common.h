@@ -82,6 +82,30 @@ AACLIP_DEV void split8x4(const float (&v)[4], f16x4& hi, uint32_t& lo8, uint32_t
   lo8 = pack_e4m3x4<SPLIT8_ACT_LO_EXP>(r[0], r[1], r[2], r[3]);
   hi8 = pack_e4m3x4<SPLIT8_ACT_HI_EXP>(v[0], v[1], v[2], v[3]);
 }
+// The same from three instructions less per value: with MODE.FP16_OVFL set the fp8 conversions SATURATE at +-448 instead
+// of returning NaN, and v_cvt_scalef32_pk_fp8_f32 divides by a power-of-two scale on the way (tools/cvt_fp8_probe.hip:
+// bit-identical to multiply + clamp + convert on every probe value).  A kernel that calls split8x4_sat must have run
+// fp8_saturate_mode() first (the mode is per wave and lasts until the wave ends; it also turns an overflowing f32 ->
+// f16 conversion into +-65504 instead of inf, which no caller here distinguishes).
+AACLIP_DEV void fp8_saturate_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+AACLIP_DEV void split8x4_sat(const float (&v)[4], f16x4& hi, uint32_t& lo8, uint32_t& hi8) {
+  typedef short i16x2 __attribute__((ext_vector_type(2)));
+  float r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (f16)v[j];
+    r[j] = v[j] - (float)hi[j];
+  }
+  constexpr float S_LO = 1.0f / (float)(1 << SPLIT8_ACT_LO_EXP);
+  i16x2 a = {0, 0};
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, r[0], r[1], S_LO, false);
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, r[2], r[3], S_LO, true);
+  lo8 = __builtin_bit_cast(uint32_t, a);
+  static_assert(SPLIT8_ACT_HI_EXP == 0, "hi8 is the plain conversion");
+  int b = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], b, true);
+  hi8 = (uint32_t)b;
+}
 // Virtual K tiles of a split8 product.  K tiles (64 wide) are taken in pairs (2i, 2i+1):
 //   NP = 4: [fp16 tile 2i] [fp16 tile 2i+1] [e4m3 tile T1: Al8 . Wh8 over both] [e4m3 tile T2: Ah8 . Wl8 over both]
 //   NP = 3: the same without T2 (weight exact in fp16)

@@ -455,12 +455,17 @@ bool gemm_routes_to_256t(int dtype, const GemmParams& p) {
   return true;
 }
 
+// split fp16: true when launch_gemm will run the 256-tile kernel -- the one whose EPI_BIAS epilogue can write the
+// attention kernel's e4m3 records (GemmParams::out_qk8)
+bool gemm_split_routes_to_256t(const GemmParams& p) { return g_gemm_variant != 1 && split256_applicable(p) && p.M >= 4096; }
+
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   if (dtype == AACLIP_F16X2) {   // split fp16: the default 256-tile kernel from M = 4096 rows, else the 128-tile kernel
-    if (g_gemm_variant != 1 && split256_applicable(p) && p.M >= 4096) {
+    if (gemm_split_routes_to_256t(p)) {
       launch_gemm256t(dtype, epi, p, s, 14);
       return;
     }
+    if (p.out_qk8) { set_launch_error("gemm: out_qk8 needs the 256-tile kernel"); return; }
     dim3 g(((p.M + 127) / 128) * (p.N / 128));
     if (p.w_exact16) launch16s<3>(epi, p, g, s);
     else launch16s<4>(epi, p, g, s);

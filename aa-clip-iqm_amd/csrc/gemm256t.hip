@@ -36,7 +36,7 @@ AACLIP_DEV float row16_sum(float x) {
   return x;
 }
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
-template <typename T, int EPI, bool SPLIT = false>
+template <typename T, int EPI, bool SPLIT = false, bool QK8 = false>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane,
                              const f32x2* ab_pre = nullptr) {
   typedef typename Elem<T>::vec4 vec4;
@@ -105,6 +105,22 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           }
           const int m = mi * 16 + c16;
           if constexpr (SPLIT && EPI == EPI_BIAS) {
+            if constexpr (QK8) {
+              // attention records for the e4m3 correction form (attention.hip, QK8): hi tile as below; the e4m3 planes
+              // of this wave's 64 columns (ONE head of q or k) share a 128-byte staging row [lo8 | hi8], which is also
+              // the record's layout in memory.  v columns (>= out_qk8) carry no correction.
+              char* sp = st + (m & 63) * 128;
+              if (n_base < p.out_qk8) {   // wave-uniform: this wave's 64 columns are one head of q or of k
+                uint32_t l8, h8;
+                split8x4_sat(vv, o, l8, h8);   // (the split kernels run fp8_saturate_mode() at entry)
+                *(uint32_t*)(sp + 8192 + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
+                *(uint32_t*)(sp + 8192 + (((4 + (nl >> 4)) ^ (m & 7)) << 4) + (nl & 12)) = h8;
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (f16)vv[j];
+              }
+              *(vec4*)(sp + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
+            } else {
             // split16 rows (attention inputs): the hi and lo tiles of a pass are staged side by side (passes 2, 3
             // reuse the LDS of passes 0, 1: a wave's LDS accesses execute in order) and stored as two row segments
             // N columns apart
@@ -118,11 +134,12 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
             char* sp = st + (m & 63) * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2;
             *(vec4*)sp = o;
             *(vec4*)(sp + 8192) = o2;
+            }
           } else if constexpr (SPLIT) {
             // split8 rows (the next product's A operand): hi tile as above; the e4m3 planes of a row share one
             // 128-byte staging row, [lo8: 64 bytes][hi8: 64 bytes], 16-byte chunks swizzled like the hi tile
             uint32_t l8, h8;
-            split8x4(vv, o, l8, h8);
+            split8x4_sat(vv, o, l8, h8);   // (the split kernels run fp8_saturate_mode() at entry)
             char* sp = st + (m & 63) * 128;
             *(vec4*)(sp + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
             *(uint32_t*)(sp + 8192 + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
@@ -146,7 +163,11 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
             T* orow = (T*)p.out + (long)row * p.ldc;
             ST_OUT((u32x4*)(orow + n_base + c * 8), vh);
             if constexpr (EPI == EPI_BIAS) {
-              ST_OUT((u32x4*)(orow + p.N + n_base + c * 8), vl);
+              if constexpr (QK8) {   // the 128-byte e4m3 record of (row, this wave's head), behind the N fp16 values
+                if (n_base < p.out_qk8) ST_OUT((u32x4*)((char*)orow + 2 * p.N + (n_base >> 6) * 128 + c * 16), vl);
+              } else {
+                ST_OUT((u32x4*)(orow + p.N + n_base + c * 8), vl);
+              }
             } else {
               // chunk c < 4: bytes [16c, 16c+16) of this wave's 64 lo8 columns; c >= 4: of its hi8 columns
               char* o8 = (char*)orow + 2 * p.N + (c >> 2) * p.N + n_base + (c & 3) * 16;
@@ -1021,11 +1042,12 @@ AACLIP_DEV f32x4 mma_e4m3k(const FragPair<f16, true>& w, const FragPair<f16, tru
 }
 template <int KIND, typename T> AACLIP_DEV f32x4 mma_e4m3k(const FragPair<T, false>&, const FragPair<T, false>&, f32x4 c, int) { return c; }
 
-template <typename T, int EPI, int NP = 0>
+template <typename T, int EPI, int NP = 0, bool QK8 = false>   // QK8: GemmParams::out_qk8 (EPI_BIAS, split operands only)
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[131072];
 
+  if (NP != 0) fp8_saturate_mode();   // the split8 epilogues convert with split8x4_sat
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
@@ -1243,7 +1265,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef MM8
 #undef QUADX
 #undef KTILE
-  epilogue256t<T, EPI, NP != 0>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
+  epilogue256t<T, EPI, NP != 0, QK8>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
 }
 
 // split fp16 (AACLIP_F16X2): the default kernel on split8 operands, 4 (3: W exact in fp16) virtual tiles per K-tile pair
@@ -1256,13 +1278,17 @@ static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
   const int total_x = patches_n * pm_x;
   dim3 gx(((total_x + 7) / 8) * 8 * PMx * PN), b(512);
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    case EPI_BIAS:
+      if (p.out_qk8) hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP, true>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1);
+      else hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1);
+      break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
     case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_RESID, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
     case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_ACT_F32, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
     case EPI_PATCH: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_PATCH, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
     default: set_launch_error("gemm: no 256-tile kernel for this epilogue");
   }
+  if (p.out_qk8 && epi != EPI_BIAS) set_launch_error("gemm: out_qk8 goes with the bias epilogue only");
 }
 
 template <typename T>

@@ -333,7 +333,6 @@ __global__ __launch_bounds__(256) void cross_rows_mfma_kernel(CrossSegs segs, co
                                                               float* __restrict__ part, int R, int rows_per_image,
                                                               int row0, int Lk, int ldx, int nseg, int slices) {
   typedef typename Elem<T>::vec8 vec8;
-  typedef typename Elem<T>::vec4 vec4;
   constexpr int RB = DK * 2, TILEB = 32 * RB, QW = DK / 4, NCQ = QW / 32, NT = QW / 16, NI = TILEB / 4096;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILEB + 8192];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

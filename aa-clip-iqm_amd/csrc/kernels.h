@@ -32,6 +32,8 @@ struct GemmParams {
   // or, with w_exact16, [N, K] (the weight is exact in fp16: the Ah.Wl product is skipped); 16-bit outputs are split
   // rows too ([M, >= 2N], ldc = row stride, lo plane N columns after the hi plane).
   int w_exact16;
+  int out_qk8;                // EPI_BIAS, split fp16, 256-tile kernel only: > 0 = the output is the attention kernel's
+                              // [hi: N fp16][per 64 columns below out_qk8: lo8 64 B | hi8 64 B] record (ldc >= (N + out_qk8 / 2) halves... see gemm256t.hip)
   int out_no_hi8;             // EPI_BIAS_GELU, split fp16: the consumer's weight is exact in fp16 -- skip the hi8 plane
 };
 
@@ -65,7 +67,10 @@ void read_attn_stamps(unsigned long long* out9, int reset);   // -DATTN_STAMP bu
 // fused softmax(q k^T) v over packed qkv [B*L, 3*H*64] (q pre-scaled) -> ctx [B*L, H*64]
 // log2q != 0: q is pre-multiplied by log2(e) as well (16-bit kernels only)
 void launch_attention(int dtype, const void* qkv, void* ctx, int B, int L, int H, int causal, int log2q,
-                      hipStream_t s, bool hi8 = true);
+                      hipStream_t s, bool hi8 = true, bool qk8 = false);
+// qk8 (split fp16, log2q, L >= 512 only): qkv rows are [q k v hi: 3D fp16][q8][k8] records of 10 D bytes (attention.hip,
+// GemmParams::out_qk8) instead of split16 rows
+bool attention_qk8_applicable(int L, int causal);
 
 // row ops (rowops.hip); D in {256, 768, 1024}
 const char* row_width_check(int D);
@@ -100,6 +105,7 @@ void launch_split_rows(const float* src, void* dst, long rows, int D, hipStream_
 // LayerNorm folding: [M][slots][2] partial (sum, sumsq) -> [M][2] (rstd, -mean*rstd)
 void launch_ln_stats_finalize(const float* partials, float* ab, long rows, int slots, int D, float eps, hipStream_t s);
 bool gemm_routes_to_256t(int dtype, const GemmParams& p);   // launch_gemm will run a kernel with the folding epilogue
+bool gemm_split_routes_to_256t(const GemmParams& p);        // split fp16: ... the 256-tile kernel (out_qk8 epilogue)
 // V-V "surgery" attention over the batch axis: regroup v [B*L,D] -> packed q|k|v rows l*B+b and back
 void launch_vv_spread(int dtype, const void* v, void* qkv, int B, int L, int D, float scale, hipStream_t s);
 void launch_vv_regroup(int dtype, const void* src, void* dst, int B, int L, int D, hipStream_t s);

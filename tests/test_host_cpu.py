@@ -299,8 +299,9 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
     # NP = 0: plain fp16 operands; NP = 4 / 3: the split-fp16 instantiations (virtual K tiles, run-time tile offsets).
     # For those a spill is worse than slow: a spilled address comes back through scratch_load + s_waitcnt vmcnt(0),
     # which drains the DMA pipeline once per tile (measured: 1.60 -> 1.35 ms per c_fc launch when the last one went).
-    for epi, np_ in [(e, n) for n in (0, 4, 3) for e in range(5)]:
-        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}ELi{np_}EEEvNS_10GemmParamsEiiiii:"
+    # (the last template flag: the QKV product writing the attention kernel's e4m3 records, GemmParams::out_qk8)
+    for epi, np_, qk8 in [(e, n, 0) for n in (0, 4, 3) for e in range(5)] + [(0, 4, 1), (0, 3, 1)]:
+        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}ELi{np_}ELb{qk8}EEEvNS_10GemmParamsEiiiii:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
         body = lines[start:end]
@@ -312,7 +313,7 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
             f"EPI {epi} NP {np_}: waterfall loop around the K-loop DMA (descriptor not provably uniform)"
         assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi} NP {np_}: spill in the K loop"
         checked += 1
-    assert checked == 15
+    assert checked == 17
 
 
 def test_tower_run_plans_one_call_with_tap_buffers(monkeypatch):
