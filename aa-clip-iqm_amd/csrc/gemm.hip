@@ -164,51 +164,55 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 
 // ------------------------------------------------------------------ fp32
 // Exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain.
-template <int EPI>
+// T = 128: 128 x 128 tile, a wave owns 64 x 64 (2 x 2 MFMA tiles).  T = 64: 64 x 64 tile, a wave owns 32 x 32 -- for small
+// grids (the IQM branch's [128..1024, 768] products under fp32 / fp16x2: 6-48 tiles of 128 on 256 CUs, each tile a serial
+// chain of K/16 x 2048 MFMA cycles): four times the workgroups and a quarter of the chain per workgroup, 85 -> ~25 us.
+// Every output element sums its k terms in the same order in both forms: results are bit-identical.
+template <int EPI, int T = 128>
 __global__ __launch_bounds__(256) void gemm32_kernel(GemmParams p) {
-  constexpr int LD = 132;
+  constexpr int LD = T + 4, NJ = T / 64, NI = T / 64;   // NJ float4 per thread and operand; NI x NI MFMA tiles per wave
   __shared__ float As[16 * LD];
   __shared__ float Ws[16 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_n = p.N >> 7;
-  const int tiles_m = (p.M + 127) >> 7;
+  const int tiles_n = p.N / T;
+  const int tiles_m = (p.M + T - 1) / T;
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
 
-  const float* ap[2];
-  const float* wp[2];
-  int srow[2], sk[2];
+  const float* ap[NJ];
+  const float* wp[NJ];
+  int srow[NJ], sk[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     int f = tid + 256 * j;
     srow[j] = f >> 2;
     sk[j] = (f & 3) * 4;
-    int ar = tm * 128 + srow[j];
+    int ar = tm * T + srow[j];
     ar = ar < p.M ? ar : p.M - 1;
     ap[j] = (const float*)p.A + (long)ar * p.lda + sk[j];
-    wp[j] = (const float*)p.W + (long)(tn * 128 + srow[j]) * p.K + sk[j];
+    wp[j] = (const float*)p.W + (long)(tn * T + srow[j]) * p.K + sk[j];
   }
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = p.K >> 4;
-  f32x4 ra[2], rw[2];
+  f32x4 ra[NJ], rw[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     ra[j] = *(const f32x4*)(ap[j]);
     rw[j] = *(const f32x4*)(wp[j]);
   }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         As[(sk[j] + e) * LD + srow[j]] = ra[j][e];
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmParams p) {
     __syncthreads();
     if (kt + 1 < nk) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         ra[j] = *(const f32x4*)(ap[j] + (kt + 1) * 16);
         rw[j] = *(const f32x4*)(wp[j] + (kt + 1) * 16);
       }
@@ -225,23 +229,27 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int k = 2 * ks + h;
-      float a0 = As[k * LD + wr * 64 + r], a1 = As[k * LD + wr * 64 + 32 + r];
-      float b0 = Ws[k * LD + wc * 64 + r], b1 = Ws[k * LD + wc * 64 + 32 + r];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[NI], b[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        a[i] = As[k * LD + wr * (T / 2) + 32 * i + r];
+        b[i] = Ws[k * LD + wc * (T / 2) + 32 * i + r];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = tm * 128 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int row = tm * T + wr * (T / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       if (row < p.M) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = tn * 128 + wc * 64 + j * 32 + r;
+        for (int j = 0; j < NI; ++j) {
+          const int col = tn * T + wc * (T / 2) + j * 32 + r;
           epi_store<EPI, float>(p, row, col, acc[i][j][e]);
         }
       }
@@ -507,6 +515,17 @@ void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   } else if (dtype == AACLIP_BF16) {
     launch16<bf16>(epi, p, g, s);
   } else {
+    if (tiles < 128) {   // fewer 128-tiles than half the CUs: 64 x 64 tiles (same sums, four times the workgroups)
+      dim3 g64(((p.M + 63) / 64) * (p.N / 64));
+      switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS, 64>), g64, dim3(256), 0, s, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS_GELU, 64>), g64, dim3(256), 0, s, p); break;
+        case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS_RESID, 64>), g64, dim3(256), 0, s, p); break;
+        case EPI_ACT_F32: hipLaunchKernelGGL((gemm32_kernel<EPI_ACT_F32, 64>), g64, dim3(256), 0, s, p); break;
+        case EPI_PATCH: hipLaunchKernelGGL((gemm32_kernel<EPI_PATCH, 64>), g64, dim3(256), 0, s, p); break;
+      }
+      return;
+    }
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS>), g, dim3(256), 0, s, p); break;
       case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm32_kernel<EPI_BIAS_GELU>), g, dim3(256), 0, s, p); break;

@@ -129,6 +129,23 @@ def test_gemm_epilogues(dev, code, shape):
     assert_close(o32, O.leaky_relu(acc), 2e-5, 1e-5, "leaky")
 
 
+def test_gemm_fp32_tile_forms_are_bit_identical(dev):
+    """The exact-fp32 GEMM has a 128 x 128-tile and a 64 x 64-tile form (small grids: csrc/gemm.hip); every output element
+    sums its k terms in the same order in both, so the same columns computed inside a wide product (128-tile form: >= 128
+    tiles) and alone (64-tile form) must agree bit for bit."""
+    lib = _lib.load()
+    M, K, NW = 200, 272, 8192
+    A = synth.randn("t.g32.a", (M, K), 1.0, 3).to(dev)
+    W = synth.randn("t.g32.w", (NW, K), K ** -0.5, 4).to(dev)
+    bias = synth.randn("t.g32.b", (NW,), 0.5, 5).to(dev)
+    wide = torch.empty(M, NW, dtype=torch.float32, device=dev)
+    _gemm(lib, dev, F32, _lib.EPI_BIAS_GELU, A, W, bias, wide)
+    for n0, n in ((0, 128), (1024, 384)):
+        alone = torch.empty(M, n, dtype=torch.float32, device=dev)
+        _gemm(lib, dev, F32, _lib.EPI_BIAS_GELU, A, W[n0:n0 + n].contiguous(), bias[n0:n0 + n].contiguous(), alone)
+        assert torch.equal(alone, wide[:, n0:n0 + n]), (n0, n)
+
+
 def _attn_ref(qkv, B, L, H, causal):
     D = H * 64
     q, k, v = qkv.double().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)

@@ -262,3 +262,64 @@ def test_attention_first_tile_far_below_zero(dev, code, L, causal):
     ref = _attn_ref(ref_in, 1, L, H, causal)
     got = ctx.float() if code == F16 else join8(ctx, D)
     assert_close(got, ref, 3e-3 if code == F16 else 4e-4, 1e-2, f"first tile -150, L={L}, causal={causal}")
+
+
+def _ref_block64(x, blk, B, L, H):
+    """One residual attention block in fp64 (reference model/transformer.py:239-258), full attention."""
+    D = x.shape[1]
+    d = lambda t: t.detach().double()
+    ln = lambda v, w, b: torch.nn.functional.layer_norm(v, (D,), d(w), d(b), 1e-5)
+    h = ln(x, blk.ln_1.weight, blk.ln_1.bias)
+    qkv = (h @ d(blk.attn.in_proj_weight).t() + d(blk.attn.in_proj_bias)).view(B, L, 3, H, 64)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    ctx = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B * L, D)
+    x = x + ctx @ d(blk.attn.out_proj.weight).t() + d(blk.attn.out_proj.bias)
+    h = ln(x, blk.ln_2.weight, blk.ln_2.bias)
+    h = h @ d(blk.mlp.c_fc.weight).t() + d(blk.mlp.c_fc.bias)
+    h = 0.5 * h * (1 + torch.erf(h / 2 ** 0.5))
+    return x + h @ d(blk.mlp.c_proj.weight).t() + d(blk.mlp.c_proj.bias)
+
+
+@pytest.mark.parametrize("shape", [(256, 520, 8), (512, 1370, 3)])
+def test_block_long_rows_take_the_e4m3_attention_form(dev, shape):
+    """Long rows on the 256-tile kernels: the QKV epilogue writes q and k as fp16 + [lo8 | hi8] e4m3 records and the
+    attention kernel runs its two correction products on the 32x32x64 scaled MFMA (csrc/attention.hip, QK8).  Against
+    fp64 on the same weights, and against the split16 form of the same block (forced by routing the products to the
+    128-tile kernels): both inside the same bound, and their difference far below plain fp16's error."""
+    from model.transformer import ResidualAttentionBlock
+    D, L, B = shape
+    H = D // 64
+    torch.manual_seed(5)
+    blk = ResidualAttentionBlock(D, H).to(dev)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            if prm.dim() > 1:
+                prm.normal_(0, 0.7 * prm.shape[1] ** -0.5)
+            else:
+                prm.normal_(0, 0.3)
+        blk.ln_1.weight.add_(1.0)
+        blk.ln_2.weight.add_(1.0)
+    x0 = torch.randn(B * L, D, device=dev)
+    x0[:, 3] += 2.0
+    ref = _ref_block64(x0.double(), blk, B, L, H)
+    outs = {}
+    lib = _lib.load()
+    with torch.no_grad():
+        for name, variant in (("qk8", 0), ("split16", 1)):
+            assert lib.aaclip_set_gemm_variant(variant) == 0
+            try:
+                xa = x0.clone()
+                engine.run_blocks(xa, [blk], B, L, H, F16X2, causal=False)
+                outs[name] = xa
+            finally:
+                lib.aaclip_set_gemm_variant(0)
+        x16 = x0.clone()
+        engine.run_blocks(x16, [blk], B, L, H, F16, causal=False)
+    e8 = float((outs["qk8"].double() - ref).abs().max())
+    e16 = float((outs["split16"].double() - ref).abs().max())
+    ef = float((x16.double() - ref).abs().max())
+    print(f"one block D{D} L{L}: |err| vs fp64: e4m3 form {e8:.2e}, split16 form {e16:.2e}, plain fp16 {ef:.2e}")
+    assert not torch.equal(outs["qk8"], outs["split16"])      # the two forms really are different code paths
+    assert_close(outs["qk8"], ref, 4e-4, 5e-4, "e4m3 attention form vs fp64")
+    assert_close(outs["split16"], ref, 4e-4, 5e-4, "split16 attention form vs fp64")
+    assert e8 < 0.25 * ef and e16 < 0.25 * ef
