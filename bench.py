@@ -49,7 +49,8 @@ PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0} 
 DTYPE_NAME = {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "fp16x2": "f16x2"}
 # fp16x2 (split fp16, include/aaclip.h AACLIP_F16X2): a GEMM accumulates the fp16 product plus two correction products on
 # the block-scaled e4m3 MFMAs (twice the fp16 rate): 2.0 fp16-MFMA time units per algorithmic unit, 1.5 where the weight
-# is exact in fp16 (one correction product); attention: 3 + 2 fp16 products = 2.5 units.  Rates and roofline fractions
+# is exact in fp16 (one correction product); attention at L >= 512: q.k^T as one fp16 product + two e4m3 correction products,
+# p.v as one fp16 product = 1.5 units (csrc/attention.hip, QK8).  Rates and roofline fractions
 # count the ALGORITHMIC flops (1013.6 GFLOP per image) against the fp16 MFMA peak; the MFMA pipe is busy
 # `mfma_time_multiple` times as long as those flops alone would keep it.
 TAGS = {0: "layernorm", 1: "qkv_gemm", 2: "attention", 3: "out_proj_gemm", 4: "c_fc_gemm", 5: "c_proj_gemm",
@@ -362,9 +363,9 @@ def run_rank(args):
                 "whole_path_tflops": round(value * gflop_img / 1e3, 1),
                 "whole_path_frac_of_mfma_peak": round(value * gflop_img / 1e3 / (peak * n_gpus), 4),
                 # share of the fp16 MFMA pipe's time the path keeps busy = algorithmic fraction x the mode's MFMA time
-                # multiple (fp16x2: GEMMs 82 % of the flops at 2.0 -- 1.5 with fp16-exact weights --, attention 18 % at 2.0)
+                # multiple (fp16x2: GEMMs 82 % of the flops at 2.0 -- 1.5 with fp16-exact weights --, attention 18 % at 1.5)
                 "whole_path_mfma_time_frac": round(value * gflop_img / 1e3 / (peak * n_gpus) * (
-                    ((0.82 * (1.5 if args.clip_weights == "fp16" else 2.0) + 0.18 * 2.0) if args.precision == "fp16x2"
+                    ((0.82 * (1.5 if args.clip_weights == "fp16" else 2.0) + 0.18 * 1.5) if args.precision == "fp16x2"
                      else 1.0)), 4),
                 "roofline": {
                     "kernel": kname + f" (mlp.c_fc, M={B}*1370, N=4096, K=1024)",
