@@ -455,3 +455,113 @@ def test_split_row_formats_on_the_host():
     q = torch.nn.Parameter(x[:, :128].half().float().contiguous())
     assert engine.CACHE.get(q, _lib.F16X2, "plain+exact").shape == (5, 512)        # K = 128: pairs of K tiles, no 3-plane form
     assert engine.dtype_code("fp16x2") == _lib.F16X2 and engine.plain_code(_lib.F16X2) == _lib.F32
+
+
+def test_iqm_cross_attention_foldings_agree_on_cpu(monkeypatch):
+    """Host algebra of the IQM visual cross-attention (model/iqm.py IQM._attend), with every engine call replaced by its
+    torch definition on the CPU: (a) the reference's order -- project every row through query_adapters, torch.cat,
+    visual_feature_proj, W_k and W_v, then attend per head (reference model/adapter.py:205-221, model/iqm.py:108-139);
+    (b) W_k, W_v and visual_feature_proj folded onto the effective queries (aaclip_cross_rows on the concatenated rows);
+    (c) query_adapters folded as well (aaclip_cross_rows_levels on the LayerNorm'ed tap rows, first row of every image
+    skipped).  All three must give the same attention output: the weights w_in / w_out that AdaptedCLIP._iqm_levels
+    concatenates, the [B, R, level, D] layout and the row0 / rows_per_image bookkeeping are what this pins."""
+    import math
+    from model.iqm import IQM
+    F32 = _lib.F32
+
+    def fake_gemm(code, epi, a, w, bias, out, act=0):
+        y = a.double() @ w.double().t()
+        if bias is not None:
+            y = y + bias.double()
+        if epi == _lib.EPI_BIAS_GELU:
+            y = 0.5 * y * (1 + torch.erf(y / math.sqrt(2)))
+        out.copy_(y.to(out.dtype))
+        return out
+
+    class FakeCache:
+        def get(self, w, code, kind=None):
+            w = w.detach().float()
+            return w.t().contiguous() if kind == "transpose" else w
+
+    def fake_head_expand(q, H, scale, code):
+        rows, D = q.shape
+        hd = D // H
+        out = torch.zeros(rows, H, D)
+        for h in range(H):
+            out[:, h, h * hd:(h + 1) * hd] = q[:, h * hd:(h + 1) * hd] * scale
+        return out.view(rows * H, D)
+
+    def fake_head_diag(full, H):
+        rows, D = full.shape[0] // H, full.shape[1]
+        hd = D // H
+        f = full.view(rows, H, D)
+        return torch.cat([f[:, h, h * hd:(h + 1) * hd] for h in range(H)], 1).contiguous()
+
+    def fake_cross_rows(qt, x, B, R, Lk, code):
+        Dk = x.shape[-1]
+        p = torch.softmax(qt.double().view(B, R, Dk) @ x.double().view(B, Lk, Dk).transpose(1, 2), -1)
+        return (p @ x.double().view(B, Lk, Dk)).float().view(B * R, Dk)
+
+    def fake_cross_rows_levels(qt, levels, B, R, rpi, row0, Lk, Dk):
+        n = len(levels)
+        q = qt.double().view(B, R, n, Dk)
+        keys = [x.double().view(B, rpi, -1)[:, row0:row0 + Lk, :Dk] for x in levels]
+        p = torch.softmax(torch.cat([torch.einsum("brd,bjd->brj", q[:, :, s], keys[s]) for s in range(n)], -1), -1)
+        out = torch.stack([torch.einsum("brj,bjd->brd", p[:, :, s * Lk:(s + 1) * Lk], keys[s]) for s in range(n)], 2)
+        return out.float().reshape(B * R, n * Dk)
+
+    def fake_small_attention(q, k, v, B, nq, Lk, H, code):
+        D = q.shape[-1]
+        hd = D // H
+        qh = q.double().view(B, nq, H, hd).transpose(1, 2)
+        kh = k.double().view(B, Lk, H, hd).transpose(1, 2)
+        vh = v.double().view(B, Lk, H, hd).transpose(1, 2)
+        return (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), -1) @ vh).transpose(1, 2).reshape(B * nq, D).float()
+
+    def fake_res_ln(a, b, ln, eps):
+        x = a if b is None else a + b
+        return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, eps)
+
+    monkeypatch.setattr(engine, "gemm", fake_gemm)
+    monkeypatch.setattr(engine, "CACHE", FakeCache())
+    monkeypatch.setattr(engine, "head_expand", fake_head_expand)
+    monkeypatch.setattr(engine, "head_diag", fake_head_diag)
+    monkeypatch.setattr(engine, "cross_rows", fake_cross_rows)
+    monkeypatch.setattr(engine, "cross_rows_levels", fake_cross_rows_levels)
+    monkeypatch.setattr(engine, "small_attention", fake_small_attention)
+    monkeypatch.setattr(engine, "residual_layernorm", fake_res_ln)
+
+    torch.manual_seed(3)
+    B, nq, H, hid, Dtap, L, nlev = 2, 2, 4, 256, 48, 9, 3          # 8 effective queries, 3 levels of 8 patch rows
+    iqm = IQM(hidden_size=hid, num_hidden_layers=1, num_attention_heads=H, encoder_hidden_size=hid,
+              text_encoder_hidden_size=hid, intermediate_size=64)
+    att = iqm.encoder.layer[0].crossattention
+    with torch.no_grad():
+        for prm in att.parameters():
+            prm.normal_(0, 0.2 if prm.dim() > 1 else 0.3)
+        att.output.LayerNorm.weight.add_(1.0)
+    wqa = [torch.randn(hid, Dtap) * 0.3 for _ in range(nlev)]                 # query_adapters[k].weight (no bias)
+    P, bp = torch.randn(hid, hid) * 0.1, torch.randn(hid) * 0.2              # visual_feature_proj
+    taps = [torch.randn(B * L, Dtap) for _ in range(nlev)]                    # ln_post(tap k), CLS row included
+    h = torch.randn(B * nq, hid)
+    with torch.no_grad():
+        # (a) the reference's order: rows projected level by level, concatenated per image, projected again
+        vis = torch.cat([(t.view(B, L, Dtap)[:, 1:] @ w.t()) for t, w in zip(taps, wqa)], 1)          # [B, nlev*(L-1), hid]
+        enc = (vis @ P.t() + bp).reshape(-1, hid)
+        Lk = nlev * (L - 1)
+        # (_attend itself takes the folded branch whenever rows of this width are given, so the unfolded order is written out)
+        q = h @ att.attention.query.weight.t() + att.attention.query.bias
+        k = enc @ att.attention.key.weight.t() + att.attention.key.bias
+        v = enc @ att.attention.value.weight.t() + att.attention.value.bias
+        ctx = fake_small_attention(q, k, v, B, nq, Lk, H, F32)
+        a = fake_res_ln(ctx @ att.output.dense.weight.t() + att.output.dense.bias, h, att.output.LayerNorm, iqm.eps)
+        # (b) W_k, W_v, visual_feature_proj folded; rows = the concatenated query_adapters outputs
+        b = iqm._attend(att, h, vis.reshape(-1, hid).contiguous(), B, nq, Lk, F32, enc_proj=(P, bp))
+        # (c) query_adapters folded too: rows = the LayerNorm'ed taps themselves
+        lv = {"rows": taps, "rows_per_image": L, "row0": 1, "keys": L - 1, "width": Dtap,
+              "w_in": torch.cat([w.t() for w in wqa], 0).contiguous(), "w_out": torch.cat(wqa, 1).contiguous()}
+        c = iqm._attend(att, h, None, B, nq, Lk, F32, enc_proj=(P, bp), enc_levels=lv)
+    assert a.shape == b.shape == c.shape == (B * nq, hid)
+    assert float(a.abs().max()) > 0.5
+    assert torch.allclose(b, a, atol=2e-5, rtol=1e-5), float((b - a).abs().max())
+    assert torch.allclose(c, a, atol=2e-5, rtol=1e-5), float((c - a).abs().max())
