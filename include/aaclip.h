@@ -28,7 +28,11 @@
  *                              weights [out, in] likewise: [Wh: in x fp16][e4m3(W * 2^6)][e4m3((W - Wh) * 2^17)]
  *                      split16 [hi: C x fp16][lo: C x fp16 = v - hi]
  *                              the packed q|k|v rows aaclip_attention reads (C = 3 * H * 64) = the output of
- *                              AACLIP_EPI_BIAS.
+ *                              AACLIP_EPI_BIAS.  (Inside aaclip_block / aaclip_blocks*, for rows of >= 512 tokens, q and k
+ *                              travel from the QKV product to the attention kernel as fp16 + a 128-byte
+ *                              [lo8 | hi8] e4m3 record per head instead, and the two correction products of q.k^T run
+ *                              on v_mfma_scale_f32_32x32x64_f8f6f4 -- a workspace-internal format, not part of this
+ *                              interface.)
  *                    e4m3 = OCP e4m3fn; the scales are fixed (activations 0.016 ... 448 and weights 2.4e-4 ... 7 keep
  *                    >= 4 significant bits in their correction operands; beyond, that element's correction degrades
  *                    towards plain fp16, never the main term).  A weight whose values are exact in fp16 (OpenAI's
