@@ -159,6 +159,9 @@ class IQM(nn.Module):
                 xbar = engine.cross_rows(qx, enc, B, nq * H, Lk, code)
                 ebar = torch.empty(B * nq * H, kin, dtype=torch.float32, device=h.device)
                 engine.gemm(code, EPI_ACT_F32, xbar.to(dt), engine.CACHE.get(pw, code), engine._f32c(pb), ebar)
+            elif enc.dtype in (torch.float16, torch.bfloat16) and enc.shape[-1] in (768, 1024):
+                # 16-bit rows: the matrix-core kernel, one segment (the anchor tokens of the text cross-attention)
+                ebar = engine.cross_rows_levels(qt, [enc], B, nq * H, Lk, 0, Lk, enc.shape[-1])
             else:
                 ebar = engine.cross_rows(qt, enc, B, nq * H, Lk, code)                           # [B*nq*H, Dk] fp32
             full = torch.empty(B * nq * H, D, dtype=torch.float32, device=h.device)
