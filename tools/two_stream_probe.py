@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--split", default="", help="comma-separated part sizes instead of equal parts, e.g. 59,5 (a big part whose "
+                    "GEMMs fill whole rounds of 256 tiles and a small one to fill the gaps)")
     args = ap.parse_args()
     import torch
     from aaclip_hip import synth
@@ -34,7 +36,13 @@ def main():
     clip = clip.to(dev).eval()
     B, P = args.batch, args.parts
     images = torch.randn(B, 3, 518, 518, device=dev)
-    parts = list(images.chunk(P))
+    if args.split:
+        sizes = [int(v) for v in args.split.split(",")]
+        assert sum(sizes) == B
+        parts = list(images.split(sizes))
+        P = len(parts)
+    else:
+        parts = list(images.chunk(P))
     streams = [torch.cuda.Stream(dev) for _ in range(P)]
 
     def one():
@@ -69,7 +77,7 @@ def main():
         same = torch.equal(torch.cat([g[0] for g in got]), ref[0])
         print(f"pooled outputs of the {P}-stream run bit-identical to the one-stream run: {same}")
         timed(one, f"one stream, B = {B}")
-        timed(multi, f"{P} streams, B = {B // P} each")
+        timed(multi, f"{P} streams, B = {[int(x.shape[0]) for x in parts]}")
         timed(lambda: multi(1.2), f"{P} streams, later ones delayed 1.2 ms")
         timed(one, f"one stream, B = {B} (again)")
 
