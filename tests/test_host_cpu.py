@@ -565,3 +565,24 @@ def test_iqm_cross_attention_foldings_agree_on_cpu(monkeypatch):
     assert float(a.abs().max()) > 0.5
     assert torch.allclose(b, a, atol=2e-5, rtol=1e-5), float((b - a).abs().max())
     assert torch.allclose(c, a, atol=2e-5, rtol=1e-5), float((c - a).abs().max())
+
+    # (d) the anchor rows: 16-bit rows of width 768 read as they are (one segment of the matrix-core row kernel)
+    torch.manual_seed(4)
+    iq2 = IQM(hidden_size=128, num_hidden_layers=1, num_attention_heads=4, encoder_hidden_size=128,
+              text_encoder_hidden_size=768, intermediate_size=64)
+    at2 = iq2.encoder.layer[0].text_crossattention
+    with torch.no_grad():
+        for prm in at2.parameters():
+            prm.normal_(0, 0.1 if prm.dim() > 1 else 0.3)
+        at2.output.LayerNorm.weight.add_(1.0)
+    Lt = 11
+    rows = (torch.randn(B * Lt, 768) * 0.7).half()
+    h2 = torch.randn(B * nq, 128)
+    with torch.no_grad():
+        q = h2 @ at2.attention.query.weight.t() + at2.attention.query.bias
+        k = rows.float() @ at2.attention.key.weight.t() + at2.attention.key.bias
+        v = rows.float() @ at2.attention.value.weight.t() + at2.attention.value.bias
+        ctx = fake_small_attention(q, k, v, B, nq, Lt, 4, F32)
+        want = fake_res_ln(ctx @ at2.output.dense.weight.t() + at2.output.dense.bias, h2, at2.output.LayerNorm, iq2.eps)
+        got = iq2._attend(at2, h2, rows, B, nq, Lt, F32)
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5), float((got - want).abs().max())
