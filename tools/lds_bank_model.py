@@ -69,6 +69,38 @@ def main():
                         addrs.append(tile_off(key, col >> 3) + (col & 7) * 2)
                     assert ways(addrs, 8, halves) == 1, ("tr", sub, s2, t, dblk)
     print("swizzle ok: DMA bijection, b128 operand reads and tr_b16 reads conflict-free")
+    cross_rows_image()
+
+
+def cross_rows_image():
+    """The LDS image of cross_rows_mfma_kernel (csrc/iqm.hip): 32 plain rows of DK * 2 bytes, 16-byte chunk index XORed by
+    cr_swz(row) -- read here from the source, so that the check follows the kernel.  Row reads of the score MFMAs (lane
+    (c16, g): key row kb*16 + c16, chunk cb + g, cb a multiple of 4) and transposed reads of the P.V MFMAs (lane 4q+p of
+    lane group g: key row kb*16 + 4g + q, chunk cbt + (p >> 1), half p & 1) must both be 1-way.  A first version took
+    bit 0 of the swizzle from row bit 3 and measured 25 % of its LDS cycles as conflicts (2-way on every row read)."""
+    import os, re
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "aa-clip-iqm_amd", "csrc", "iqm.hip")).read()
+    m = re.search(r"AACLIP_DEV int cr_swz\(int row\) \{ return (.*?); \}", src)
+    assert m, "cr_swz not found in csrc/iqm.hip"
+    expr = m.group(1)
+    swz = lambda row: eval(expr, {"row": row})
+    halves = [list(range(0, 32)), list(range(32, 64))]
+    for rb in (2048, 1536):
+        for kb in (0, 1):
+            for cb in range(0, rb // 16 - 3, 4):
+                addrs = [(kb * 16 + (l & 15)) * rb + (((cb + (l >> 4)) ^ swz(kb * 16 + (l & 15))) << 4) for l in range(64)]
+                assert ways(addrs, 16, B128_GROUPS) == 1, ("cross_rows b128", rb, kb, cb)
+            for cbt in range(0, rb // 16 - 1, 2):
+                addrs = []
+                for l in range(64):
+                    c16, g = l & 15, l >> 4
+                    row = kb * 16 + 4 * g + (c16 >> 2)
+                    addrs.append(row * rb + (((cbt + ((c16 & 3) >> 1)) ^ swz(row)) << 4) + (c16 & 1) * 8)
+                assert ways(addrs, 8, halves) == 1, ("cross_rows tr", rb, kb, cbt)
+        # the DMA writes LDS linearly and applies the same XOR on the source side: a bijection as long as the XOR stays
+        # inside a 16-chunk block of the row
+        assert all(0 <= swz(r) < 16 for r in range(32)) and (rb // 16) % 16 == 0
+    print("cross_rows image ok: row reads and transposed reads conflict-free for 2048- and 1536-byte rows")
 
 if __name__ == "__main__":
     main()
