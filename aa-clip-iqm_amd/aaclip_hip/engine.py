@@ -50,8 +50,13 @@ def torch_dtype(code: int) -> torch.dtype:
 
 
 def plain_code(code: int) -> int:
-    """The arithmetic type of the side paths that have no split-fp16 kernels (IQM branch): exact fp32 there."""
+    """The arithmetic type of the side paths that have no split-fp16 GEMM kernels (IQM branch): fp32 products there.
+    (Not everything on that branch is then exact fp32: with the tap levels folded, the visual cross-attention reads the
+    fp16 halves of the split8 tap rows and runs p.v with fp16 probabilities, csrc/iqm.hip cross_rows_mfma_kernel.)"""
     return F32 if code == F16X2 else code
+
+
+CROSS_ROWS_MAX_SEGMENTS = 4      # csrc/iqm.hip cross_rows_levels_check: tap levels one aaclip_cross_rows_levels call takes
 
 
 # split fp16 (include/aaclip.h AACLIP_F16X2, csrc/common.h): fixed power-of-two scales of the e4m3 correction planes

@@ -132,6 +132,57 @@ def synth_clip_state_dict(cfg: ClipCfg, seed: int = 111) -> Dict[str, torch.Tens
     return sd
 
 
+# Channels of the visual residual stream that `outlier_edit` turns into "massive activation" channels, with the constant
+# each receives from block 6's MLP bias (real ViT-L/14 checkpoints carry a handful of such channels in the hundreds).
+OUTLIER_CHANNELS = ((7, 120.0), (133, -80.0), (402, 300.0), (518, -500.0), (777, 600.0), (1001, -150.0))
+OUTLIER_FROM_BLOCK = 5            # 0-based: the stream carries the outliers from the output of the 6th block on
+OUTLIER_GELU_UNITS = {8: ((100, 700.0), (2000, 1500.0)), 15: ((3500, 2500.0), (64, 460.0))}   # block -> (hidden unit, c_fc bias)
+
+
+def outlier_edit(sd: Dict[str, torch.Tensor], cfg: "ClipCfg", seed: int = 111) -> Dict[str, torch.Tensor]:
+    """A copy of a synthetic CLIP state dict edited so that the VISUAL tower behaves like a trained checkpoint with
+    outlier channels (all other parity records are Gaussian-initialised weights):
+
+      * block 6's `mlp.c_proj` writes constants of +-80 ... +-600 into six channels of the residual stream (bias) and
+        its rows for those channels are 6x larger, so the outliers also vary by token; block 12's `attn.out_proj` does
+        the same for two more channels at +-40.  From there on every LayerNorm statistic is dominated by them.
+      * every LayerNorm behind them (ln_1 / ln_2 of blocks 7..24, ln_post) has gamma x5..x10 on the ordinary channels
+        (a trained model compensates the shrunken normalised values this way) and gamma x0.02..x0.1 on the outlier channels.
+      * blocks 9 and 16 have hidden units whose pre-activation sits at 460 ... 2500, i.e. GELU outputs beyond the
+        e4m3 range (448) of the split8 correction planes, feeding `c_proj` columns scaled by 0.02.
+
+    Deterministic (per-tensor generators like every other synthetic weight); used by tests/golden/make_golden_full4o.py
+    for the reference run and by tests/test_gpu_configs.py for the build's run of the same weights."""
+    out = {k: v.clone() for k, v in sd.items()}
+    d, layers = cfg.vision.width, cfg.vision.layers
+    pre = "visual.transformer.resblocks."
+    ch = torch.tensor([c for c, _ in OUTLIER_CHANNELS])
+    val = torch.tensor([v for _, v in OUTLIER_CHANNELS])
+    b = OUTLIER_FROM_BLOCK
+    out[f"{pre}{b}.mlp.c_proj.bias"][ch] += val
+    out[f"{pre}{b}.mlp.c_proj.weight"][ch] *= 6.0
+    ch2 = torch.tensor([55, 640])
+    out[f"{pre}11.attn.out_proj.bias"][ch2] += torch.tensor([40.0, -40.0])
+    out[f"{pre}11.attn.out_proj.weight"][ch2] *= 8.0
+    allch = torch.cat([ch, ch2])
+
+    def regain(name):
+        g = 5.0 + 5.0 * torch.rand(d, generator=_gen("outlier." + name, seed))
+        g[allch] = 0.02 + 0.08 * torch.rand(allch.numel(), generator=_gen("outlier.small." + name, seed))
+        out[name] *= g
+
+    for i in range(b + 1, layers):
+        regain(f"{pre}{i}.ln_1.weight")
+        regain(f"{pre}{i}.ln_2.weight")
+    regain("visual.ln_post.weight")
+    for blk, units in OUTLIER_GELU_UNITS.items():
+        for j, bias in units:
+            out[f"{pre}{blk}.mlp.c_fc.bias"][j] = bias
+            out[f"{pre}{blk}.mlp.c_fc.weight"][j] *= 4.0
+            out[f"{pre}{blk}.mlp.c_proj.weight"][:, j] *= 0.02
+    return out
+
+
 def _xavier(name: str, out_f: int, in_f: int, seed: int) -> torch.Tensor:
     return uniform(name, (out_f, in_f), math.sqrt(6.0 / (in_f + out_f)), seed)
 

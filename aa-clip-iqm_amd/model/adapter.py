@@ -98,14 +98,19 @@ class AdaptedCLIP(nn.Module):
         n_levels = len(self.levels)
         blocks = list(v.transformer.resblocks)
         iqm_on = text_embeddings is not None
-        icode = engine.plain_code(code)     # the IQM side branch has no split-fp16 kernels: exact fp32 under fp16x2
+        # the IQM side branch has no split-fp16 GEMMs: under fp16x2 its products are exact fp32, EXCEPT the visual
+        # cross-attention of the folded form below, which reads the fp16 halves of the tap rows as keys / values and
+        # forms p.v with fp16 probabilities on the MFMA (csrc/iqm.hip cross_rows_mfma_kernel)
+        icode = engine.plain_code(code)
         dt = engine.torch_dtype(icode)
         P = L - 1
         # 16-bit towers without the LeakyReLU in query_adapters: every step from the LayerNorm'ed tap rows to the keys and
         # values of the IQM cross-attention is linear, so the branch reads those rows as they are (_iqm_levels); otherwise
         # the levels are projected and concatenated like the reference does (_iqm_project_level)
+        # (aaclip_cross_rows_levels takes at most 4 segments: more tap levels keep the projected form)
         fold_levels = (iqm_on and not self.relu and code in (engine.F16, engine.BF16, engine.F16X2)
-                       and 2 * self.iqm.num_attention_heads <= 16 and xs.shape[-1] in (768, 1024))
+                       and 2 * self.iqm.num_attention_heads <= 16 and xs.shape[-1] in (768, 1024)
+                       and n_levels <= engine.CROSS_ROWS_MAX_SEGMENTS)
         ln_rows = []
         vis_cat = (torch.empty(B, n_levels * P, self.iqm_hidden_size, dtype=dt, device=xs.device)
                    if iqm_on and not fold_levels else None)

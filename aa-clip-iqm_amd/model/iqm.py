@@ -198,7 +198,9 @@ class IQM(nn.Module):
         engine.require_gpu(query_embeds, "IQM")
         if code is None:
             code = engine.dtype_code(getattr(self, "precision", "fp32"))
-        code = engine.plain_code(code)          # no split-fp16 kernels on this side branch: exact fp32 under fp16x2
+        # no split-fp16 GEMMs on this side branch: fp32 products under fp16x2 (with encoder_levels the visual
+        # cross-attention still reads fp16 key / value rows and fp16 probabilities, see AdaptedCLIP.forward)
+        code = engine.plain_code(code)
         dt = engine.torch_dtype(code)
         B, nq, D = query_embeds.shape
         if (encoder_hidden_states is None and encoder_levels is None) or text_encoder_hidden_states is None:

@@ -70,6 +70,10 @@ def parse_args(argv=None):
                     help="synthetic CLIP weights as drawn (fp32) or rounded through fp16 like OpenAI's stored checkpoint "
                          "(fp16x2 then skips the weight-lo product of those matrices: 2 MFMA products instead of 3)")
     ap.add_argument("--workload", default="tower", choices=["tower", "full"])
+    ap.add_argument("--feed", default="resident", choices=["resident", "pinned"],
+                    help="resident: the batch stays in HBM (the metric's definition).  pinned: every step computes on a "
+                         "batch that was copied from pinned host memory on a side stream while the previous step ran "
+                         "(two device buffers, one event each way; reference test_last.py:70-71 feeds from a DataLoader)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -119,6 +123,61 @@ def launch_ranks(n, argv):
             if p.poll() is None:
                 p.kill()
     return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# overlapped input feed (reference test_last.py:70-71: every batch arrives from the host)
+# ----------------------------------------------------------------------------------------------------------------
+class PinnedFeed:
+    """Double-buffered host -> device feed.  Two pinned host batches stand for what a DataLoader with pin_memory hands
+    over; batch i is copied into device buffer i & 1 on a side stream while batch i - 1 computes on the other buffer:
+      copy stream:     wait free[k] -> H2D copy -> record ready[k]
+      compute stream:  wait ready[k] -> step on buffer k -> record free[k] -> start the copy of batch i + 2
+    On CPU (the gloo rehearsal of the launcher) there are no streams: the same calls in the same order, plain copies."""
+
+    def __init__(self, torch, dev, shape, seed, rehearse=False):
+        self.torch, self.dev, self.rehearse = torch, dev, rehearse
+        g = torch.Generator()
+        g.manual_seed(seed)
+        self.host = [torch.randn(*shape, generator=g) for _ in range(2)]
+        self.dbuf = [torch.empty(*shape, device=dev) for _ in range(2)]
+        self.issued = 0        # batches whose copy has been started
+        self.taken = 0         # batches handed to the compute stream
+        if not rehearse:
+            self.host = [h.pin_memory() for h in self.host]
+            self.copy_stream = torch.cuda.Stream(dev)
+            self.ready = [torch.cuda.Event() for _ in range(2)]
+            self.free = [torch.cuda.Event() for _ in range(2)]
+            for e in self.free:
+                e.record(torch.cuda.current_stream(dev))
+        self._start_copy()
+        self._start_copy()
+
+    def _start_copy(self):
+        k = self.issued & 1
+        if self.rehearse:
+            self.dbuf[k].copy_(self.host[k])
+        else:
+            with self.torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self.free[k])
+                self.dbuf[k].copy_(self.host[k], non_blocking=True)
+                self.ready[k].record(self.copy_stream)
+        self.issued += 1
+
+    def next(self):
+        """The next batch, valid on the current stream."""
+        k = self.taken & 1
+        if not self.rehearse:
+            self.torch.cuda.current_stream(self.dev).wait_event(self.ready[k])
+        self.taken += 1
+        return self.dbuf[k]
+
+    def done(self):
+        """The step on the batch last handed out has been queued: its buffer may be refilled once that step is over."""
+        k = (self.taken - 1) & 1
+        if not self.rehearse:
+            self.free[k].record(self.torch.cuda.current_stream(self.dev))
+        self._start_copy()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -176,8 +235,10 @@ def run_rank(args):
         x = torch.randn(B, 768, generator=gen)
         w = torch.randn(768, 768, generator=gen)
 
+        cur = {"images": x}
+
         def step():
-            gathered[0] = gather_rows(x @ w)
+            gathered[0] = gather_rows(cur["images"] @ w)
             return gathered[0]
         step_tower = step_full = step
     else:
@@ -203,14 +264,15 @@ def run_rank(args):
         clip, model = build(args.precision)
         images = torch.randn(B, 3, 518, 518, generator=gen, device=dev, dtype=torch.float32)
         anchors = torch.nn.functional.normalize(torch.randn(768, 2, generator=gen, device=dev), dim=0)
+        cur = {"images": images}
 
         def step_tower():
-            pooled, taps = clip.encode_image(images, [6, 12, 18, 24])
+            pooled, taps = clip.encode_image(cur["images"], [6, 12, 18, 24])
             gathered[0] = gather_rows(pooled)          # ONE RCCL all-gather per step (no-op at N=1)
             return taps
 
         def step_full():
-            seg, det, _ = model(images)
+            seg, det, _ = model(cur["images"])
             amap = FU.calculate_anomaly_map(seg, anchors, 518, domain="Industrial")
             score = FU.image_score(det, anchors)
             gathered[0] = gather_rows(score)           # ONE RCCL all-gather per step (no-op at N=1)
@@ -219,7 +281,20 @@ def run_rank(args):
         print(f"[bench] model + data ready in {time.time() - t0:.1f}s; B={B}/GPU, {args.precision}, "
               f"workload={args.workload}, ranks={ranks_seen}", file=sys.stderr)
 
-    step = step_tower if args.workload == "tower" else step_full
+    step_resident = step_tower if args.workload == "tower" else step_full
+
+    def make_fed_step(inner):
+        """`inner` on batches that arrive from pinned host memory, copy overlapped with the previous step"""
+        feed = PinnedFeed(torch, dev, tuple(cur["images"].shape), 977 + rank, rehearse)
+
+        def fed():
+            cur["images"] = feed.next()
+            out = inner()
+            feed.done()
+            return out
+        return fed
+
+    step = make_fed_step(step_resident) if args.feed == "pinned" else step_resident
 
     def sync():
         if not rehearse:
@@ -285,6 +360,35 @@ def run_rank(args):
             sync()
             key = "full_images_per_s" if args.workload == "tower" else "tower_images_per_s"
             extra[key] = round(2 * B / (time.perf_counter() - t1), 2)
+            if args.feed == "resident":
+                # the same step on batches that arrive from pinned host memory (copy on a side stream under the
+                # previous step), next to the resident-data rate of the same process: what the H2D feed costs
+                fed = make_fed_step(step_resident)
+                nf = max(3, min(args.steps, 10))
+                for _ in range(2):
+                    fed()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(nf):
+                    fed()
+                fence()
+                dt_fed = time.perf_counter() - t1
+                for _ in range(2):
+                    step_resident()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(nf):
+                    step_resident()
+                fence()
+                dt_res = time.perf_counter() - t1
+                extra["input_feed"] = {
+                    "mode": "pinned host batches, H2D copy on a side stream overlapped with the previous step "
+                            "(two device buffers, one event each way)",
+                    "steps": nf, "fed_images_per_s_this_rank": round(nf * B / dt_fed, 2),
+                    "resident_images_per_s_this_rank": round(nf * B / dt_res, 2),
+                    "loss_pct": round(100.0 * (dt_fed - dt_res) / dt_res, 2),
+                    "bytes_per_step_per_rank": B * 3 * 518 * 518 * 4}
+                cur["images"] = images
             if n_gpus == 1:
                 # the other arithmetic modes on the same workload and batch, so that one line shows all three:
                 # fp32 (the reference's type, exact), fp16x2 (16-bit MFMAs inside the north-star tolerance), fp16
@@ -339,6 +443,8 @@ def run_rank(args):
                 "image": "518x518",
                 "parallelism": f"dp{n_gpus}",
                 "gflop_per_image": gflop_img,
+                "input": ("batch resident in HBM" if args.feed == "resident" else
+                          "every batch copied from pinned host memory on a side stream under the previous step"),
                 "clip_weights": ("random fp32" if args.clip_weights == "fp32" else
                                  "random, rounded through fp16 (exact in fp16, like OpenAI's stored checkpoint)"),
             },
@@ -380,9 +486,15 @@ def run_rank(args):
                     "flop_per_launch": fc_flop,
                     "mfma_time_multiple": (1.5 if args.clip_weights == "fp16" else 2.0) if args.precision == "fp16x2" else 1.0,
                 },
-                "parity_vs_north_star": parity_fields(args.precision),
+                "parity_vs_north_star": parity_in_run(clip, model, args.precision, args.clip_weights, dev, torch),
             })
         result.update(extra)
+        if n_gpus == 1 and not args.no_extra and not rehearse:
+            try:    # the text side (reported separately, never part of images/s)
+                result["text_anchors"] = text_anchors_leg(model, lib, dev, torch, cfg, args.precision,
+                                                          not args.no_cpu_baseline)
+            except Exception as e:   # noqa: BLE001
+                result["text_anchors"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if n_gpus == 1 and not args.no_cpu_baseline and not rehearse:
             try:
                 result["cpu_baseline"] = cpu_baseline(cfg, args.workload)
@@ -394,28 +506,60 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-def parity_fields(precision):
-    """Where this arithmetic mode stands against BASELINE.json's tolerance (|a - b| <= 1e-3 + 1e-2 |b| vs the fp32
-    reference) on the full-size B = 4 golden record: the largest error-to-bound ratio over raw taps, pooled embedding,
-    per-level and summed pre-blur maps, as measured by tests/test_gpu_configs.py on MI355X and committed under
-    profiles/ (> 1 means OUTSIDE the tolerance).  The timed path is bit-identical to that B = 4 run per image."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_parity_errors.json")), reverse=True):
-        try:
-            with open(path) as f:
-                e = json.load(f)
-        except (OSError, ValueError):
-            continue
-        keys = [k for k in e if k.startswith(precision + ".b4.") and ("tap" in k or "map_pre_blur" in k or "pooled" in k)]
-        feats = [k for k in e if k.startswith(precision + ".b4.") and ("seg" in k or k.endswith(".det"))]
-        if not keys:
-            continue
-        worst = max(keys, key=lambda k: e[k]["max_ratio_to_north_star"])
-        return {"taps_and_maps_max_ratio": round(e[worst]["max_ratio_to_north_star"], 3), "worst_output": worst,
-                "features_max_ratio": round(max(e[k]["max_ratio_to_north_star"] for k in feats), 3) if feats else None,
-                "inside_north_star": e[worst]["max_ratio_to_north_star"] <= 1.0,
-                "source": os.path.relpath(path, REPO)}
-    return None
+def parity_in_run(clip, model, precision, clip_weights, dev, torch):
+    """Where the arithmetic mode being timed stands against BASELINE.json's tolerance (|a - b| <= 1e-3 + 1e-2 |b| vs
+    the fp32 reference), MEASURED IN THIS RUN: the four images of the reference's full-size B = 4 golden record
+    (tests/golden/full4.npz; full4h.npz when the CLIP weights are the fp16-exact ones) go through the model objects
+    that were just timed, and the largest error-to-bound ratio is taken over raw taps + pooled embedding
+    (`encode_image`) and per-level + summed pre-blur maps (`AdaptedCLIP.forward` + the map kernel); unit seg tokens and
+    the det token are reported beside it.  > 1 means OUTSIDE the tolerance.  A few seconds; the goldens are data the
+    reference produced (tests/golden/make_golden_full4*.py), nothing of the reference runs here."""
+    import numpy as np
+    from aaclip_hip import engine, synth
+    gold = os.path.join(REPO, "tests", "golden")
+    name = "full4h" if clip_weights == "fp16" else "full4"
+    try:
+        g = np.load(os.path.join(gold, name + ".npz"))
+        anchors = torch.from_numpy(np.load(os.path.join(gold, "full.npz"))["full.anchors_bottle"]).to(dev)
+    except OSError as e:
+        return {"error": f"golden record missing: {e}"[:200]}
+    img = synth.synth_images(4, 518, seed=int(g[name + ".seed"])).to(dev)
+    ratios = {}
+
+    def ratio(key, got, ref):
+        got, ref = got.detach().double().cpu().reshape(-1), ref.double().reshape(-1)
+        ok = bool(torch.isfinite(got).all())
+        ratios[key] = float(((got - ref).abs() / (1e-3 + 1e-2 * ref.abs())).max()) if ok else float("inf")
+
+    def sampled(key, t):
+        return t.detach().reshape(-1).cpu()[torch.from_numpy(g[key + ".idx"])], torch.from_numpy(g[key + ".val"])
+
+    with torch.no_grad():
+        seg, det, _ = model(img)
+        for i in range(4):
+            raw = engine.anomaly_map([seg[i]], anchors, 37, 1, 1.0)
+            ratio(f"map_pre_blur{i}", raw, torch.from_numpy(g[f"{name}.map_pre_blur{i}"]))
+        fused = engine.anomaly_map(list(seg), anchors, 37, 1, 1.0)
+        ratio("map_pre_blur_sum", fused, torch.from_numpy(g[f"{name}.map_pre_blur_sum"]))
+        feats = {}
+        for i in range(4):
+            a, b = sampled(f"{name}.seg{i}", seg[i])
+            feats[f"seg{i}"] = float(((a.double() - b.double()).abs() / (1e-3 + 1e-2 * b.double().abs())).max())
+        d_ref = torch.from_numpy(g[f"{name}.det"]).double()
+        feats["det"] = float(((det.double().cpu() - d_ref).abs() / (1e-3 + 1e-2 * d_ref.abs())).max())
+        if name == "full4":   # the fp16-exact record holds no taps
+            pooled, taps = clip.encode_image(img, [6, 12, 18, 24])
+            for k, t in zip((6, 12, 18, 24), taps):
+                a, b = sampled(f"full4.tap{k}", t)
+                ratio(f"tap{k}", a, b)
+            ratio("pooled", pooled, torch.from_numpy(g["full4.pooled"]))
+    worst = max(ratios, key=ratios.get)
+    return {"taps_and_maps_max_ratio": round(ratios[worst], 3), "worst_output": f"{precision}.b4.{worst}",
+            "features_max_ratio": round(max(feats.values()), 3),
+            "inside_north_star": max(max(ratios.values()), max(feats.values())) <= 1.0,
+            "per_output_ratio": {k: round(v, 3) for k, v in sorted(ratios.items())},
+            "source": f"measured in this run: B = 4 golden images through the timed model vs tests/golden/{name}.npz "
+                      "(reference outputs)"}
 
 
 def companion(precision, build, args, B, dev, torch):
@@ -445,12 +589,98 @@ def companion(precision, build, args, B, dev, torch):
     dt = time.perf_counter() - t
     gflop = GFLOP_TOWER if args.workload == "tower" else GFLOP_FULL
     rate = steps * B / dt
+    out = _companion_fields(precision, rate, steps, B, dt, gflop, clip32, model32, args, dev, torch)
     del clip32, model32
     torch.cuda.empty_cache()
+    return out
+
+
+def _companion_fields(precision, rate, steps, B, dt, gflop, clip32, model32, args, dev, torch):
     return {"dtype": DTYPE_NAME[precision], "value": round(rate, 2), "unit": "images/s", "steps": steps, "batch": B,
             "ms_per_step": round(dt / steps * 1e3, 2), "whole_path_tflops": round(rate * gflop / 1e3, 1),
             "frac_of_mfma_peak": round(rate * gflop / 1e3 / PEAK_TFLOPS[precision], 4),
-            "peak_tflops": PEAK_TFLOPS[precision], "parity_vs_north_star": parity_fields(precision)}
+            "peak_tflops": PEAK_TFLOPS[precision],
+            "parity_vs_north_star": parity_in_run(clip32, model32, precision, args.clip_weights, dev, torch)}
+
+
+GFLOP_SENTENCE = 13.57   # adapted text tower, per 77-token sentence
+
+
+def text_anchors_leg(model, lib, dev, torch, cfg, precision, with_cpu):
+    """The text side of the path, timed on its own ("report separately, exclude from img/s"): all 240 MVTec
+    prompt sentences (15 classes x 16; reference forward_utils.py:138-192) through
+    forward_utils.get_adapted_text_embedding -- ONE batched AdaptedCLIP.encode_text call (M = 240 x 77 = 18 480 rows, 12
+    causal blocks of width 768 with the text adapters, reference model/adapter.py:273-304) plus the segmented means --
+    in the arithmetic mode being benchmarked.  `call_ms` is the whole call (host tokenisation from the prompt table, the
+    kernels, the 30 anchor means) with the device synchronised on both sides, median of 5 after one warm-up;
+    `kernel_ms` the HIP-event time of the library's kernels by class for one call.  Next to it the CPU oracle's
+    `adapted_encode_text` on the host cores for ONE class (16 sentences), which is how the reference runs it
+    (one class at a time, forward_utils.py:185-192)."""
+    import statistics
+    import forward_utils as FU
+    from aaclip_hip import _lib, synth
+    from dataset.constants import CLASS_NAMES
+    names = list(CLASS_NAMES["MVTec"])
+    n_sent = 16 * len(names)
+
+    def call():
+        return FU.get_adapted_text_embedding(model, "MVTec", dev)
+
+    with torch.no_grad():
+        anchors = call()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            call()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t)
+        cap = 12 * 12 + 64
+        _lib.check(lib.aaclip_profile_begin(0x7F, cap), "profile_begin")
+        call()
+        torch.cuda.synchronize(dev)
+        ms, tg = (C.c_float * cap)(), (C.c_int * cap)()
+        n = lib.aaclip_profile_end(ms, tg, cap)
+    br = {}
+    for i in range(n):
+        br[TAGS[tg[i]]] = br.get(TAGS[tg[i]], 0.0) + ms[i]
+    med = statistics.median(ts)
+    kernel_total = sum(br.values())
+    ok = all(bool(torch.isfinite(a).all()) and tuple(a.shape) == (768, 2) for a in anchors.values())
+    out = {"sentences": n_sent, "classes": len(names), "rows": n_sent * 77, "dtype": DTYPE_NAME[precision],
+           "call_ms": round(med * 1e3, 3), "sentences_per_s": round(n_sent / med, 1),
+           "tflops": round(n_sent * GFLOP_SENTENCE / med / 1e3, 1),
+           "kernel_ms": {k: round(v, 3) for k, v in sorted(br.items())}, "kernel_ms_total": round(kernel_total, 3),
+           "kernel_tflops": round(n_sent * GFLOP_SENTENCE / (kernel_total * 1e-3) / 1e3, 1) if kernel_total > 0 else None,
+           "gflop_per_sentence": GFLOP_SENTENCE, "anchors_finite": ok,
+           "kernels": "M = 18 480 rows: the 256-tile GEMMs of the visual tower (K = 768 / 3072), the 128-query "
+                      "causal attention kernel (L = 77), LayerNorm / adapter-mix row kernels"}
+    if with_cpu:
+        from oracle import aaclip_oracle as O
+        from model.tokenizer import tokenize
+        sd = synth.synth_clip_state_dict(cfg, 111)
+        ta = synth.synth_text_adapter_state_dict(cfg, seed=111)
+        sentences = [s_ for grp in FU.class_sentences("MVTec", names[0]) for s_ in grp]
+        tok = tokenize(sentences)
+        all_cores = min(os.cpu_count() or 1, 32)
+        runs = []
+        with torch.no_grad():
+            for threads in sorted({min(4, all_cores), all_cores}):
+                torch.set_num_threads(threads)
+                O.adapted_encode_text(tok, sd, ta, cfg.text.heads)
+                t3 = []
+                for _ in range(3):
+                    t = time.perf_counter()
+                    O.adapted_encode_text(tok, sd, ta, cfg.text.heads)
+                    t3.append(time.perf_counter() - t)
+                m3 = statistics.median(t3)
+                runs.append({"threads": threads, "s_per_class": round(m3, 3),
+                             "sentences_per_s": round(len(sentences) / m3, 2)})
+        out["cpu_baseline"] = {"kind": "port", "unit": "sentences/s", "value": runs[-1]["sentences_per_s"],
+                               "cores": all_cores, "runs": runs,
+                               "sample": "oracle adapted_encode_text, the 16 sentences of one class, 1 warm-up + median "
+                                         "of 3 per thread setting"}
+    return out
 
 
 def traffic_fields(precision, batch, clip_weights="fp32"):

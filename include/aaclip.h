@@ -273,9 +273,6 @@ int aaclip_adapter_mix(float* x, const float* a, long rows, int D, float weight,
  * (AACLIP_EPI_BIAS for 16-bit key / value / patch operands, AACLIP_EPI_BIAS_GELU for intermediate_query,
  * AACLIP_EPI_ACT_F32 with a bias for the 2-row query side).  The entry points below are what is left. */
 
-/* softmax(q k^T * scale) v per (image, head) for nq <= 4 queries over Lk <= 8192 keys: the core of
- * IQM_MultiHeadAttention.forward (reference model/iqm.py:108-139; masks are all-zero on this path, dropout is the
- * identity in eval).  q, out [B, nq, H*hd] fp32; k, v [B*Lk, H*hd] in kv_dtype; hd a multiple of 4, <= 128. */
 /* Cross-attention of IQM without the key / value projections of the patch rows (reference model/iqm.py:108-139 with
  * encoder_hidden_states = the 4 x 1369 projected patch rows; the reference projects every row through W_k and W_v):
  *   scores_j = q_h . (W_k[h] x_j + b_k[h]) / sqrt(d) = (W_k[h]^T q_h / sqrt(d)) . x_j + const  (softmax-invariant)
@@ -305,6 +302,9 @@ int aaclip_cross_rows_levels(int x_dtype, const float* qt, const void* const* x,
                              void* stream);
 int aaclip_head_expand(int dtype, const float* q, void* qm, long rows, int H, int D, float scale, void* stream);
 int aaclip_head_diag(const float* full, float* ctx, long rows, int H, int D, void* stream);
+/* softmax(q k^T * scale) v per (image, head) for nq <= 4 queries over Lk <= 8192 keys: the core of
+ * IQM_MultiHeadAttention.forward (reference model/iqm.py:108-139; masks are all-zero on this path, dropout is the
+ * identity in eval).  q, out [B, nq, H*hd] fp32; k, v [B*Lk, H*hd] in kv_dtype; hd a multiple of 4, <= 128. */
 int aaclip_small_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int B, int nq, int Lk,
                            int H, int hd, float scale, void* stream);
 /* out = LayerNorm(a + b) over the last dimension D (b may be NULL): IQM_SelfOutput / IQM_Output (reference

@@ -151,3 +151,37 @@ def test_bench_rehearsal_of_the_full_workload_two_ranks():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["rows_all_gathered_per_step"] == 8
     assert "full AA-CLIP" in d["config"]["workload"] and d["value"] is None
     assert d["threads_per_rank"] == max(1, (os.cpu_count() or 1) // 2)
+
+
+def test_pinned_feed_hands_out_alternating_batches_in_order():
+    """bench.PinnedFeed on CPU (the rehearsal form: same call order, plain copies): batch i is host batch i & 1, a
+    buffer is only refilled after done() of the step that used it, and two copies are always in flight ahead."""
+    import sys
+    import torch
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    import bench
+    feed = bench.PinnedFeed(torch, torch.device("cpu"), (3, 5), seed=1, rehearse=True)
+    assert feed.issued == 2 and feed.taken == 0
+    for i in range(7):
+        x = feed.next()
+        assert torch.equal(x, feed.host[i & 1]) and x is feed.dbuf[i & 1]
+        assert feed.issued == i + 2                   # the refill of THIS buffer has not started yet
+        feed.done()
+        assert feed.issued == i + 3 and feed.taken == i + 1
+    assert not torch.equal(feed.host[0], feed.host[1])
+
+
+def test_bench_rehearsal_with_the_pinned_feed_two_ranks():
+    """--feed pinned through the launcher (2 ranks, gloo rehearsal): every step takes its batch from the feed."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--feed", "pinned", "--rehearse-cpu"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["rows_all_gathered_per_step"] == 16 and "pinned host" in d["config"]["input"]

@@ -276,6 +276,35 @@ def test_iqm_rejects_other_anchor_layouts(dev):
             model(img, text_embeddings=torch.randn(cfg.embed_dim, 2, device=dev))
 
 
+def test_iqm_five_tap_levels_take_the_projected_form(dev):
+    """aaclip_cross_rows_levels takes at most 4 segments (engine.CROSS_ROWS_MAX_SEGMENTS).  A model with FIVE tap levels
+    on a 16-bit tower of width 1024 (where the folded form would otherwise be chosen) must run the per-level projection
+    instead of failing inside forward (round-3 advisor finding), and agree with the exact-fp32 tower, which never folds."""
+    from model.model import CLIP
+    from model.adapter import AdaptedCLIP
+    cfg = synth.tiny_cfg()
+    outs = {}
+    for precision in ("fp32", "fp16"):
+        clip = CLIP(768, dict(image_size=70, layers=5, width=1024, patch_size=14),
+                    dict(context_length=77, vocab_size=cfg.vocab_size, width=cfg.text.width, heads=cfg.text.heads,
+                         layers=cfg.text.layers), precision=precision)
+        torch.manual_seed(5)
+        for prm in clip.parameters():
+            if prm.dim() > 1:
+                torch.nn.init.normal_(prm, std=0.02)
+        torch.manual_seed(6)
+        model = AdaptedCLIP(clip, image_adapt_until=2, levels=[1, 2, 3, 4, 5], relu=False, text_adapt_until=1)
+        model = model.to(dev).eval()
+        assert len(model.levels) == 5 > engine.CROSS_ROWS_MAX_SEGMENTS
+        img = synth.synth_images(2, 70, seed=7).to(dev)
+        te = torch.nn.functional.normalize(torch.randn(2, 768, 2, generator=torch.Generator().manual_seed(3)), dim=1).to(dev)
+        with torch.no_grad():
+            seg, det, iq = model(img, text_embeddings=te)
+        assert len(seg) == 5 and iq.last_hidden_state.shape == (2, 2, 768)
+        outs[precision] = iq.last_hidden_state.float().cpu()
+    close(outs["fp16"], outs["fp32"], 3e-2, 3e-2, "5-level IQM branch, fp16 vs fp32 tower")
+
+
 def test_harness_fuses_text_and_iqm_maps_like_the_reference(dev, tmp_path):
     """test_last.get_predictions with the IQM branch on (reference test_last.py:53-158): maps = 0.6 * text map + 0.4 * IQM
     map; checked on the exact-fp32 path against the oracle's two maps for a few images of a synthetic MVTec tree."""

@@ -125,6 +125,29 @@ def test_full_encode_image(golden_full, full):
     sampled(golden_full, "full.tap24", taps[1], atol=2e-4, rtol=1e-3)
 
 
+def test_outlier_record_pins_the_oracle_too():
+    """tests/golden/full4o.npz: the reference on synth.outlier_edit weights (residual-stream channels at +-600, GELU
+    outputs at 2500).  The oracle's fp32 restatement must reproduce the reference there as well (first two images:
+    rows are independent, and the record samples the flattened [4, 1370, 1024] taps)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "full4o.npz"))
+    cfg = synth.ClipCfg()
+    sd = synth.outlier_edit(synth.synth_clip_state_dict(cfg, 111), cfg, 111)
+    # the edit is what its docstring says
+    assert float(sd["visual.transformer.resblocks.5.mlp.c_proj.bias"].abs().max()) > 590
+    assert float(sd["visual.transformer.resblocks.15.mlp.c_fc.bias"].max()) == 2500.0
+    img = synth.synth_images(2, 518, seed=int(g["full4o.seed"]))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        pooled, taps = O.encode_image(img, sd, cfg.vision.heads, [6, 24])
+    close(pooled, g["full4o.pooled"][:2], atol=1e-4, rtol=1e-3)
+    for k, t in zip((6, 24), taps):
+        idx, val = T(g[f"full4o.tap{k}.idx"]), T(g[f"full4o.tap{k}.val"])
+        keep = idx < t.numel()
+        assert float(val[keep].abs().max()) > 500
+        close(t.reshape(-1)[idx[keep]], val[keep], atol=2e-4, rtol=1e-3)
+
+
 # ---------------------------------------------------------------------------------------------
 # "CLIP surgery" tap path (reference transformer.py:102-152,406-425), golden from the reference
 # ---------------------------------------------------------------------------------------------

@@ -26,7 +26,10 @@ done
 if [ $PREC = fp16x2 ]; then NPS=$([ $CW = fp16 ] && echo 3 || echo 4); ATT="attn16s_kernel"; else NPS=0; ATT="attn16x2_kernel"; fi
 # (the counter database holds MANGLED kernel names: gemm16_256x_kernel<_Float16, EPI, NP> = ...IDF16_Li<EPI>ELi<NP>E...)
 declare -A SUB=( [qkv]="gemm16_256x_kernelIDF16_Li0ELi${NPS}E" [c_fc]="gemm16_256x_kernelIDF16_Li1ELi${NPS}E" [resid]="gemm16_256x_kernelIDF16_Li2ELi${NPS}E" [attn]="$ATT" )
-for K in qkv c_fc resid attn; do
+# out_proj and c_proj are ONE instantiation (EPI_BIAS_RESID) launched alternately, out_proj first in every block
+SUB[out_proj]="${SUB[resid]}@0/2"
+SUB[c_proj]="${SUB[resid]}@1/2"
+for K in qkv c_fc out_proj c_proj attn; do
   python3 tools/rocpd_summary.py pmcjson $OUT/${TAG}_${PREC}_${K}_pmc.json "${SUB[$K]}" $DBS > $OUT/pmc_$TAG/${PREC}_${K}_summary.log 2>&1 || true
   echo "== $K (${SUB[$K]})"; tail -16 $OUT/pmc_$TAG/${PREC}_${K}_summary.log
 done

@@ -46,12 +46,23 @@ def pmcjson(out, sub, dbs):
     doc = {"kernel_substring": sub, "counters": {}, "passes": [],
            "kernel_revision": kernel_source_revision(("attention.hip", "gemm256t.hip", "gemm.hip", "common.h",
                                                       "mma16.h", "kernels.h"))}
+    # "<substring>@i/n": of the matching dispatches (in launch order) only every n-th, starting at the i-th -- two
+    # products that share one kernel instantiation (out_proj and c_proj: both EPI_BIAS_RESID, launched alternately)
+    pick = None
+    if "@" in sub:
+        sub, sel = sub.rsplit("@", 1)
+        pick = tuple(int(v) for v in sel.split("/"))
+        doc["kernel_substring"] = sub
+        doc["dispatch_selection"] = f"dispatch {pick[0]} of every {pick[1]} matching launches, in launch order"
     for path in dbs:
         db = sqlite3.connect(path)
         rows = db.execute("select dispatch_id, counter_name, value, duration, kernel_name, vgpr_count, "
                           "accum_vgpr_count, sgpr_count, lds_block_size, grid_size, workgroup_size "
                           "from counters_collection where kernel_name like ? order by dispatch_id",
                           (f"%{sub}%",)).fetchall()
+        if pick and rows:
+            order = {d: i for i, d in enumerate(sorted({r[0] for r in rows}))}
+            rows = [r for r in rows if order[r[0]] % pick[1] == pick[0]]
         if not rows:
             doc["passes"].append({"db": os.path.basename(path), "launches": 0})
             continue
