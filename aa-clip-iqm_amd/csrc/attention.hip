@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[sub][e] = LOG2Q ? -m2 : 0.f;
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;   // (an inline constant as the first MFMA's C operand: no v_mov)
       if constexpr (QK8) {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -364,13 +364,14 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
         const i32x8 ql8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, ql[0]), __builtin_bit_cast(i32x4, ql[1]), 0, 1, 2, 3, 4, 5, 6, 7);
         const i32x8 qh8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, ql[2]), __builtin_bit_cast(i32x4, ql[3]), 0, 1, 2, 3, 4, 5, 6, 7);
         constexpr int S_LO = (127 - SPLIT8_ACT_LO_EXP) * 0x01010101, S_ONE = 127 * 0x01010101;   // e8m0 block scales
-        s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kl8, qh8, s[sub], 0, 0, 0, S_LO, 0, S_ONE);
-        s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kh8, ql8, s[sub], 0, 0, 0, S_ONE, 0, S_LO);
+        // the fp16 product first: its chain starts from the inline constant 0 (the scaled MFMA wants C in registers)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const vec8 ah = *(const vec8*)(sb + koff[ks] + sub * 4096);
           s[sub] = Elem<f16>::mma32(ah, qh[ks], s[sub]);
         }
+        s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kl8, qh8, s[sub], 0, 0, 0, S_LO, 0, S_ONE);
+        s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kh8, ql8, s[sub], 0, 0, 0, S_ONE, 0, S_LO);
       } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -383,9 +384,13 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
       }
       if (!LOG2Q) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] = fmaf(s[sub][e], LOG2E, -m2);
+        for (int e = 0; e < 16; ++e) s[sub][e] *= LOG2E;
       }
     }
+    // Round 4: the scores stay RAW (relative to zero) until the exponent.  Before, every chain started from -m (32 v_mov per
+    // tile to re-initialise the accumulators) and a row whose maximum grew paid 32 more v_sub to re-base them; now the
+    // reference is subtracted once, where the exponent needs it (32 v_sub per tile, always), and a new maximum only
+    // rescales o and l.  Exact re-basing as before: the largest probability of a row is 2^0 when it is formed.
     const int k0 = kt * 64;
     const bool need_mask = (k0 + 64 > L) || (causal && (k0 + 63 > q0));
     if (need_mask) {
@@ -403,32 +408,37 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s[sub][e]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    {   // the other 32-lane half's maximum: v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip on the
+        // critical path); inline asm for the reason given at attn16x2_kernel's xhalf_max
+      float b2 = mt;
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mt), "+v"(b2));
+      mt = fmaxf(mt, b2);
+    }
     const bool first = kt == 0;
-    if (first || __any(mt > 0.f)) {
-      const float delta = first ? mt : fmaxf(mt, 0.f);
-      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // tile 0: l and o are still zero
-      m2 += delta;
+    if (first || __any(mt > m2)) {
+      const float mn = first ? mt : fmaxf(mt, m2);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(m2 - mn);   // tile 0: l and o are still zero
+      m2 = mn;
       l *= alpha;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
     }
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float pv = __builtin_amdgcn_exp2f(s[sub][e]);
+        float pv = __builtin_amdgcn_exp2f(s[sub][e] - m2);
         s[sub][e] = pv;
         rs += pv;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    {
+      float b2 = rs;
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(rs), "+v"(b2));
+      rs += b2;
+    }
     l += rs;
 
 #pragma unroll
@@ -446,7 +456,10 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
             i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + part * 16384));
             i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(vp + part * 16384 + 8 * 128));
             i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            o[db] = Elem<f16>::mma32(__builtin_bit_cast(vec8, both), pf, o[db]);
+            // accumulator tied in place: through the builtin hipcc gave these MFMAs destination tuples different from o
+            // and copied all 32 registers of o back once per tile (16 v_mov_b64; tools' ISA histogram, round 4).  The
+            // s_nop covers the VALU-write (pf: v_cvt_pk) -> MFMA-read distance the compiler can no longer see.
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(o[db]) : "v"(both), "v"(pf));
           }
         }
       }
@@ -455,18 +468,18 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
   stage(0, 0);
   wait_vm0();
   __syncthreads();
-  for (int kt = 0; kt < nkt; kt += 2) {
-    if (kt + 1 < nkt) stage(1, kt + 1);
-    tile(smem, kt);
-    wait_vm0();
-    __syncthreads();
-    if (kt + 1 >= nkt) break;
-    if (kt + 2 < nkt) stage(0, kt + 2);
-    tile(smem + STAGE, kt + 1);
+  // ONE tile per loop trip, the stage chosen at run time: with the two-tile body hipcc kept o in different register
+  // tuples in the two halves and copied all 32 registers across once per tile
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    tile(smem + cur * STAGE, kt);
     wait_vm0();
     __syncthreads();
   }
 
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last P.V MFMAs (inline asm) have written o before VALU reads it
   if (qi < L) {
     const float inv = 1.0f / l;
     f16* dst = ctx + ((long)b * L + qi) * 2 * D + head * 64;

@@ -400,7 +400,11 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
 
 static int g_tail_peel = 0;  // measured: not a win (the 128-tile kernel is too slow for the peeled rows)
 void set_tail_peel(int v) { g_tail_peel = v; }
-static int g_gemm_variant = 0;  // 0 automatic, 1 force the 128-tile kernel; more in the measurement library only
+// 0 automatic, 1 force the 128-tile kernel, 80 / 81 force the 8-wave 256 x 256 kernel / the 4-wave 256 x 128 half-tile kernel
+// where 0 would take the other one (both compute bit-identical results); more in the measurement library only
+static int g_gemm_variant = 0;
+static constexpr int DEFAULT_256 = 14;   // launch_gemm256t kernel id of variant 0: 14 = 8 waves, 256 x 256; 15 = half tiles
+static int big_kernel_id() { return g_gemm_variant == 80 ? 14 : (g_gemm_variant == 81 ? 15 : DEFAULT_256); }
 
 static thread_local const char* g_launch_err = nullptr;
 void set_launch_error(const char* msg) { if (!g_launch_err) g_launch_err = msg; }
@@ -423,9 +427,9 @@ bool set_gemm_variant(int v) {
 #ifdef AACLIP_MEASURE
   // 2..5 = 256-tile kernels on 32x32x16 MFMAs (gemm256.hip), 6..60 = the 16x16x32 family incl. timing ablations and
   // the stamp build (gemm256t.hip), 70 = persistent tiles (gemm256z.hip)
-  const bool ok = v >= 0 && (v <= 60 || v == 70);
+  const bool ok = v >= 0 && (v <= 60 || v == 70 || v == 80 || v == 81);
 #else
-  const bool ok = v == 0 || v == 1;
+  const bool ok = v == 0 || v == 1 || v == 80 || v == 81;
 #endif
   if (ok) g_gemm_variant = v;
   return ok;
@@ -445,20 +449,20 @@ static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t
     launch_gemm256t(dtype, epi, p, s, g_gemm_variant - 6);
     return;
   }
-  if (g_gemm_variant >= 2) {
+  if (g_gemm_variant >= 2 && g_gemm_variant < 80) {
     // 32x32x16 kernels: 2 DMA at the phase start, 3 DMA between the MFMAs, 4/5 timing ablations
     launch_gemm256(dtype, epi, p, s, g_gemm_variant == 2 ? 0 : g_gemm_variant - 2);
     return;
   }
 #endif
-  launch_gemm256t(dtype, epi, p, s, 14);
+  launch_gemm256t(dtype, epi, p, s, big_kernel_id());
 }
 
 // True when launch_gemm will run one of the 16x16x32 256-tile kernels (gemm256t.hip) on the whole problem:
 // those are the kernels whose epilogue implements the LayerNorm-folding options of GemmParams.
 bool gemm_routes_to_256t(int dtype, const GemmParams& p) {
   if (dtype == AACLIP_F32 || dtype == AACLIP_F16X2 || !gemm256_applicable(dtype, p) || p.M < 4096) return false;
-  if (!(g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 60))) return false;   // > 1: measurement library
+  if (!(g_gemm_variant == 0 || g_gemm_variant >= 80 || (g_gemm_variant >= 6 && g_gemm_variant <= 60))) return false;   // 2..70: measurement library
   if (g_tail_peel) return false;
   return true;
 }
@@ -470,7 +474,7 @@ bool gemm_split_routes_to_256t(const GemmParams& p) { return g_gemm_variant != 1
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   if (dtype == AACLIP_F16X2) {   // split fp16: the default 256-tile kernel from M = 4096 rows, else the 128-tile kernel
     if (gemm_split_routes_to_256t(p)) {
-      launch_gemm256t(dtype, epi, p, s, 14);
+      launch_gemm256t(dtype, epi, p, s, big_kernel_id());
       return;
     }
     if (p.out_qk8) { set_launch_error("gemm: out_qk8 needs the 256-tile kernel"); return; }
@@ -481,7 +485,7 @@ void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   }
   // variants: 0 automatic (256-tile kernels from M = 4096 rows), 1 the 128-tile kernel, >= 2 (measurement library) 256-tile
   // kernels at any M
-  if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && (g_gemm_variant >= 2 || p.M >= 4096)) {
+  if (g_gemm_variant != 1 && gemm256_applicable(dtype, p) && ((g_gemm_variant >= 2 && g_gemm_variant < 80) || p.M >= 4096)) {
     // Tail peeling: 256x256 tiles run one per CU in rounds of 256.  When the last round would be
     // less than 60 % full, the rows of that partial round go to the 128-tile kernel instead (two
     // workgroups per CU, finer granularity); both kernels produce bit-identical results.

@@ -12,6 +12,7 @@
 //     as for the 32x32x16 one (tools/lds_bank_model.py).
 // Operand roles are swapped as in the other kernel (W rows = MFMA A operand), so a
 // lane holds output column m = lane&15 and rows n = 4*(lane>>4) + j of each 16x16 tile.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 #include "mma16.h"
@@ -36,7 +37,8 @@ AACLIP_DEV float row16_sum(float x) {
   return x;
 }
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
-template <typename T, int EPI, bool SPLIT = false, bool QK8 = false>
+// NWC = waves along N: 4 for the 256 x 256 tile of 8 waves, 2 for the 256 x 128 half tile of 4 waves (gemm16_256h_kernel)
+template <typename T, int EPI, bool SPLIT = false, bool QK8 = false, int NWC = 4>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane,
                              const f32x2* ab_pre = nullptr) {
   typedef typename Elem<T>::vec4 vec4;
@@ -45,8 +47,8 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
   // GEMMs 15 % that way, with the K loop unchanged in source).
   asm volatile("" : "+v"(lane));
   const int c16 = lane & 15, q4 = lane >> 4;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int m_base = tm * 256 + wr * 128, n_base = tn * 256 + wc * 64;
+  const int wr = NWC == 4 ? wave >> 2 : wave >> 1, wc = wave & (NWC - 1);
+  const int m_base = tm * 256 + wr * 128, n_base = tn * (NWC * 64) + wc * 64;
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
     __syncthreads();  // every wave is done reading the operand tiles
     char* st = smem + wave * 16384;  // this wave's 128 x 64 tile of T: rows of 128 B, 16-B chunk ^= (m & 7)
@@ -252,7 +254,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           pq = row16_sum(pq);
           if (live && cc == 0) {
             const f32x2 st2 = {ps, pq};
-            *(f32x2*)(p.stats_out + (orow[it] * (p.N >> 6) + (tn * 4 + wc)) * 2) = st2;
+            *(f32x2*)(p.stats_out + (orow[it] * (p.N >> 6) + (tn * NWC + wc)) * 2) = st2;
           }
         }
       }
@@ -1268,6 +1270,265 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   epilogue256t<T, EPI, NP != 0, QK8>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Half-tile kernel (round 4): 256 x 128 tile, 4 waves (2 M x 2 N, 128 x 64 of C per wave as above), TWO workgroups per
+// CU (80 KiB of LDS each), so that one workgroup's prologue / epilogue runs beside the other's K loop -- the 8-wave
+// kernel above owns its CU and spends 29 % of a tile's life outside the K loop with the matrix pipe idle
+// (profiles/r04_*).  tools/kloop_skeleton.hip measured the economy first: the K loop of any
+// kernel fed by buffer_load ... lds is bound by the PIECES per MFMA (a 1 KiB piece costs its CU ~46 cycles of DMA
+// throughput), a lone workgroup of 4 waves already draws that rate, and 12 pieces per 64 MFMAs (this tile) sustain
+// 69 % of the bare MFMA rate against 72-76 % for 8 (the 256 x 256 tile) -- a few percent of K-loop rate for the overlap.
+//   * One wave per SIMD per workgroup: a wave hides its own LDS latency.  Fragments are refilled IN PLACE behind the last
+//     MFMA that reads them (A side: fm[t] right after the four MFMAs of row tile t) or into the N-side set that is dead
+//     (as in the kernel above), so the register budget is the 8-wave kernel's.
+//   * LDS: A double-buffered (2 x 32 KiB), W single-buffered (16 KiB; weights come from L2, 3 phases of flight are
+//     enough).  Chunks: A0 / A1 = the row halves a phase reads (16 KiB, 4 pieces per wave), B0 / B1 (8 KiB, 2 pieces).
+//   * Per K tile (phases = output quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0), 16 MFMAs each):
+//       issue    P0: B0(t+1)   P1: B1(t+1)             P2: A0(t+2)   P3: A1(t+2)
+//       read     P0: B1(t)     P1: A1(t) (in place)    P2: --        P3: B0(t+1), A0(t+1) (in place)
+//       confirm (counted vmcnt at the phase end, then s_barrier) the chunk(s) the NEXT phase reads; P1 needs neither.
+//     DMA instructions of one wave complete in order, issue order = A0 A1 B0 B1 of tile 0, A0 A1 of tile 1, then the
+//     table: the counts below follow from it.
+// Same products, same K order per accumulator as the 8-wave kernel: results are bit-identical to it.
+template <typename T, int EPI, int NP = 0, bool QK8 = false>
+__global__ __launch_bounds__(256, 2) void gemm16_256h_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
+  typedef typename Elem<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[81920];   // [A stage 0: 32 KiB][A stage 1: 32 KiB][W: 16 KiB]
+
+  if (NP != 0) fp8_saturate_mode();   // the split8 epilogues convert with split8x4_sat
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_m = (p.M + 255) >> 8;
+  int tm, tn;
+  {
+    const int P = PM * PN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gp = (j / P) * 8 + xcd, local = j % P;
+    if (gp >= total_patches) return;
+    const int pm = gp / patches_n, pn = gp - pm * patches_n;
+    tm = pm * PM + local / PN;
+    tn = pn * PN + local % PN;
+    if (tm >= tiles_m) return;
+  }
+  if (stagger > 0 && blockIdx.x < 512 && (blockIdx.x & 256)) {
+    // The two workgroups of a CU start together and, left alone, stay in phase: both in their K loops, both in their
+    // epilogues -- nothing overlaps.  The second workgroup of every CU (the dispatcher fills all CUs once before it
+    // doubles up: ids 256..511 of the first 512) therefore starts `stagger` cycles per K tile late, about half a tile's
+    // life; the offset then persists (a workgroup that ends late is replaced late).
+    const long long target = (long long)stagger * vtile_count<NP>(p.K);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(32);
+  }
+  const int ldw = NP == 4 ? 2 * p.K : (NP == 3 ? p.K + (p.K >> 1) : p.K);   // W row stride in halves
+  // DMA pieces (1 KiB = 8 rows of the tile image): wave w fetches pieces w + 4m, which all share ONE lane pattern
+  // (tile_src_id depends on the piece index mod 4 only), so a piece is (this lane's offset) + (scalar: 32m rows)
+  int srcA, srcW;
+  {
+    int row, chunk;
+    tile_src_id(wave * 64 + lane, row, chunk);
+    srcA = (row * (int)p.lda + chunk * 8) * 2;
+    srcW = (row * ldw + chunk * 8) * 2;
+  }
+  const T* baseA = uniform_ptr((const T*)p.A + (long)tm * 256 * p.lda);
+  const T* baseW = uniform_ptr((const T*)p.W + (long)tn * 128 * ldw);
+  // rows past M are outside the descriptor and read as zero (no clamp: the scalar row offsets need none)
+  const long bytesA = ((long)p.M - (long)tm * 256) * p.lda * 2;
+  const int recA = (int)(bytesA < 0x7FFFFFF0L ? bytesA : 0x7FFFFFF0L);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, __builtin_amdgcn_readfirstlane(recA), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
+  const int rA32 = __builtin_amdgcn_readfirstlane(32 * (int)p.lda * 2), rW32 = __builtin_amdgcn_readfirstlane(32 * ldw * 2);
+  int offM[2][2], offN[2][2];   // [ks][tile parity]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      offM[ks][par] = tile_off_id(wr * 128 + par * 16 + c16, 4 * ks + q4);
+      offN[ks][par] = 65536 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  f32x2 ab_pre[8];
+  const bool fold_pre = NP == 0 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.row_ab != nullptr;
+  if (fold_pre) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      int row = tm * 256 + wr * 128 + mi * 16 + c16;
+      row = row < p.M ? row : p.M - 1;
+      ab_pre[mi] = *(const f32x2*)(p.row_ab + 2L * row);
+    }
+  }
+
+  const int nk = vtile_count<NP>(p.K);   // (virtual) K tiles
+  int sc_pack = (127 - SPLIT8_ACT_LO_EXP) | ((127 - SPLIT8_W_HI_EXP) << 8) | ((127 - SPLIT8_W_LO_EXP) << 16) |
+                ((127 - SPLIT8_ACT_HI_EXP) << 24);
+  (void)sc_pack;
+#define DMA(rs, src, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (dst)), 16, src, so, 0, 0);
+// piece j (0..3) of A chunk `sub` of tile kt into stage st: m = {0, 1, 4, 5}[j] + 2 sub; piece j (0..1) of W chunk `sub`: m = 2j + sub
+// (offsets go through plain int locals: a template-dependent expression as a direct argument makes the builtin call
+// type-dependent, and the HOST pass then drops the kernel's stub without a diagnostic)
+#define PA(sub, j, st, kt) { int kd; const int m_ = ((j) & 1) + 4 * ((j) >> 1) + 2 * (sub); \
+    const int so_ = vtile_off<NP>(kt, p.K, kd) + m_ * rA32; const int ds_ = (st) * 32768 + (wave + 4 * m_) * 1024; DMA(rsA, srcA, ds_, so_) }
+#define PW(sub, j, kt) { int kd; const int m_ = 2 * (j) + (sub); \
+    const int so_ = vtile_off<NP>(kt, p.K, kd) + m_ * rW32; const int ds_ = 65536 + (wave + 4 * m_) * 1024; DMA(rsW, srcW, ds_, so_) }
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define BAR __builtin_amdgcn_s_barrier();
+#define PINB __builtin_amdgcn_sched_barrier(0);
+#define ODD_OFF(off) ({ int o_; asm volatile("v_xor_b32 %0, 0x80, %1" : "=v"(o_) : "v"(off)); o_ + 2048; })
+// row tile t (0..3) of A half a from the A stage at sb; N-side tiles of W half b
+#define LD_M1(sb, a, t)                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      fm[t].set(ks, *(const vec8*)((sb) + ((NP != 0 && ((t) & 1)) ? ODD_OFF(offM[ks][0]) : offM[ks][(t) & 1]) + ((a) * 2 + ((t) >> 1)) * 4096));
+#define LD_N(FN, b)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 2; ++t) \
+      FN[t].set(ks, *(const vec8*)(smem + ((NP != 0 && t == 1) ? ODD_OFF(offN[ks][0]) : offN[ks][t]) + (b) * 4096));
+#define MM(FN, a, b, t, u, ks) acc[4 * (a) + (t)][2 * (b) + (u)] = Mma16<T>::mma(FN[u].get(ks), fm[t].get(ks), acc[4 * (a) + (t)][2 * (b) + (u)]);
+#define MM8(FN, a, b, t, u, KIND) acc[4 * (a) + (t)][2 * (b) + (u)] = mma_e4m3k<(KIND) == 1 ? 1 : 2>(FN[u], fm[t], acc[4 * (a) + (t)][2 * (b) + (u)], sc_pack);
+// the MFMAs of row tile t of a quadrant (KIND literal: 0 fp16 tile, 1 / 2 e4m3 correction tiles)
+#define ROWT(FN, a, b, t, KIND)                                                              \
+  if ((KIND) != 0) { MM8(FN, a, b, t, 0, KIND) MM8(FN, a, b, t, 1, KIND) }                   \
+  else { MM(FN, a, b, t, 0, 0) MM(FN, a, b, t, 1, 0) MM(FN, a, b, t, 0, 1) MM(FN, a, b, t, 1, 1) }
+// one K tile: FB0 holds B0(kt) on entry and fm holds A0(kt); FB1 receives B1(kt) and then B0(kt+1)
+#define KTILE(kt, FB0, FB1, KIND)                                                             \
+  {                                                                                           \
+    const int cur = (kt) & 1, nxt = cur ^ 1;                                                  \
+    const bool more1 = (kt) + 1 < nk, more2 = (kt) + 2 < nk;                                  \
+    const char* sa = smem + cur * 32768;                                                      \
+    const char* sn = smem + nxt * 32768;                                                      \
+    /* P0 (A0,B0): read B1(kt); issue B0(kt+1); confirm A1(kt) */                             \
+    LD_N(FB1, 1)                                                                              \
+    PINB                                                                                      \
+    ROWT(FB0, 0, 0, 0, KIND) PINB                                                             \
+    if (more1) PW(0, 0, (kt) + 1)                                                             \
+    ROWT(FB0, 0, 0, 1, KIND) PINB                                                             \
+    if (more1) PW(0, 1, (kt) + 1)                                                             \
+    ROWT(FB0, 0, 0, 2, KIND) PINB                                                             \
+    ROWT(FB0, 0, 0, 3, KIND) PINB                                                             \
+    WAIT_LGKM(0);                                                                             \
+    if (more1) WAIT_VM(14); else WAIT_VM(4);                                                  \
+    BAR                                                                                       \
+    /* P1 (A0,B1): A1(kt) replaces A0(kt) tile by tile; issue B1(kt+1) */                      \
+    ROWT(FB1, 0, 1, 0, KIND) LD_M1(sa, 1, 0) PINB                                             \
+    if (more1) PW(1, 0, (kt) + 1)                                                             \
+    ROWT(FB1, 0, 1, 1, KIND) LD_M1(sa, 1, 1) PINB                                             \
+    if (more1) PW(1, 1, (kt) + 1)                                                             \
+    ROWT(FB1, 0, 1, 2, KIND) LD_M1(sa, 1, 2) PINB                                             \
+    ROWT(FB1, 0, 1, 3, KIND) LD_M1(sa, 1, 3) PINB                                             \
+    /* P2 (A1,B1): issue A0(kt+2); confirm B0(kt+1), A0(kt+1) */                              \
+    if (more2) PA(0, 0, cur, (kt) + 2)                                                        \
+    ROWT(FB1, 1, 1, 0, KIND) PINB                                                             \
+    if (more2) PA(0, 1, cur, (kt) + 2)                                                        \
+    ROWT(FB1, 1, 1, 1, KIND) PINB                                                             \
+    if (more2) PA(0, 2, cur, (kt) + 2)                                                        \
+    ROWT(FB1, 1, 1, 2, KIND) PINB                                                             \
+    if (more2) PA(0, 3, cur, (kt) + 2)                                                        \
+    ROWT(FB1, 1, 1, 3, KIND) PINB                                                             \
+    if (more1) { if (more2) WAIT_VM(6); else WAIT_VM(2); }                                    \
+    BAR                                                                                       \
+    /* P3 (A1,B0): read B0(kt+1) into the set B1 vacated; A0(kt+1) replaces A1(kt); issue A1(kt+2); confirm B1(kt+1) */ \
+    if (more1) LD_N(FB1, 0)                                                                   \
+    PINB                                                                                      \
+    if (more2) PA(1, 0, cur, (kt) + 2)                                                        \
+    ROWT(FB0, 1, 0, 0, KIND) if (more1) LD_M1(sn, 0, 0) PINB                                  \
+    if (more2) PA(1, 1, cur, (kt) + 2)                                                        \
+    ROWT(FB0, 1, 0, 1, KIND) if (more1) LD_M1(sn, 0, 1) PINB                                  \
+    if (more2) PA(1, 2, cur, (kt) + 2)                                                        \
+    ROWT(FB0, 1, 0, 2, KIND) if (more1) LD_M1(sn, 0, 2) PINB                                  \
+    if (more2) PA(1, 3, cur, (kt) + 2)                                                        \
+    ROWT(FB0, 1, 0, 3, KIND) if (more1) LD_M1(sn, 0, 3) PINB                                  \
+    if (more1) { WAIT_LGKM(8); if (more2) WAIT_VM(8); else WAIT_VM(0); }                      \
+    BAR                                                                                       \
+  }
+
+  // prologue: all of tile 0 and the A chunks of tile 1, in the order the counted waits assume
+  PA(0, 0, 0, 0) PA(0, 1, 0, 0) PA(0, 2, 0, 0) PA(0, 3, 0, 0)
+  PA(1, 0, 0, 0) PA(1, 1, 0, 0) PA(1, 2, 0, 0) PA(1, 3, 0, 0)
+  PW(0, 0, 0) PW(0, 1, 0) PW(1, 0, 0) PW(1, 1, 0)
+  if (nk > 1) {
+    PA(0, 0, 1, 1) PA(0, 1, 1, 1) PA(0, 2, 1, 1) PA(0, 3, 1, 1)
+    PA(1, 0, 1, 1) PA(1, 1, 1, 1) PA(1, 2, 1, 1) PA(1, 3, 1, 1)
+  }
+  FragPair<T, NP != 0> fm[4], fnX[2], fnY[2];
+  if (nk > 1) WAIT_VM(8); else WAIT_VM(0);      // A0, A1, B0, B1 of tile 0 have landed (this wave's pieces)
+  BAR
+  LD_N(fnX, 0)
+  LD_M1(smem, 0, 0) LD_M1(smem, 0, 1) LD_M1(smem, 0, 2) LD_M1(smem, 0, 3)
+  WAIT_LGKM(0);
+  BAR                                           // every wave holds B0(0): the slot may take B0(1)
+  if constexpr (NP == 0) {
+    for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
+      KTILE(kt, fnX, fnY, 0)
+      KTILE(kt + 1, fnY, fnX, 0)
+    }
+  } else if constexpr (NP == 4) {          // per pair of K tiles: fp16, fp16, Al8.Wh8, Ah8.Wl8
+    for (int kt = 0; kt < nk; kt += 4) {
+      KTILE(kt, fnX, fnY, 0)
+      KTILE(kt + 1, fnY, fnX, 0)
+      KTILE(kt + 2, fnX, fnY, 1)
+      KTILE(kt + 3, fnY, fnX, 2)
+    }
+  } else {                                 // weight exact in fp16: fp16, fp16, Al8.Wh8; two periods per trip
+    for (int kt = 0; kt < nk; kt += 6) {
+      KTILE(kt, fnX, fnY, 0)
+      KTILE(kt + 1, fnY, fnX, 0)
+      KTILE(kt + 2, fnX, fnY, 1)
+      KTILE(kt + 3, fnY, fnX, 0)
+      KTILE(kt + 4, fnX, fnY, 0)
+      KTILE(kt + 5, fnY, fnX, 1)
+    }
+  }
+#undef DMA
+#undef PA
+#undef PW
+#undef WAIT_VM
+#undef WAIT_LGKM
+#undef BAR
+#undef PINB
+#undef ODD_OFF
+#undef LD_M1
+#undef LD_N
+#undef MM
+#undef MM8
+#undef ROWT
+#undef KTILE
+  epilogue256t<T, EPI, NP != 0, QK8, 2>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
+}
+
+// launcher of the half-tile kernel: 8 x PN patches of 256 x 128 tiles per XCD (64 workgroups = the 2 per CU an XCD holds)
+template <typename T, int NP>
+static void launch_h(int epi, const GemmParams& p, hipStream_t s) {
+  const int tiles_n = p.N / 128, tiles_m = (p.M + 255) / 256;
+  int PN = 1;
+  for (int c : {8, 6, 4, 3, 2}) if (tiles_n % c == 0) { PN = c; break; }
+  const int patches_n = tiles_n / PN, PMx = 8;
+  const int pm_x = (tiles_m + PMx - 1) / PMx;
+  const int total_x = patches_n * pm_x;
+  dim3 gx(((total_x + 7) / 8) * 8 * PMx * PN), b(256);
+  static const int stg = getenv("AACLIP_H_STAGGER") ? atoi(getenv("AACLIP_H_STAGGER")) : 1400;   // cycles per K tile
+  switch (epi) {
+    case EPI_BIAS:
+      if constexpr (NP != 0) {
+        if (p.out_qk8) { hipLaunchKernelGGL((gemm16_256h_kernel<T, EPI_BIAS, NP, true>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break; }
+      }
+      hipLaunchKernelGGL((gemm16_256h_kernel<T, EPI_BIAS, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg);
+      break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256h_kernel<T, EPI_BIAS_GELU, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256h_kernel<T, EPI_BIAS_RESID, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256h_kernel<T, EPI_ACT_F32, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_256h_kernel<T, EPI_PATCH, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, stg); break;
+    default: set_launch_error("gemm: no 256-tile kernel for this epilogue");
+  }
+  if (p.out_qk8 && (epi != EPI_BIAS || NP == 0)) set_launch_error("gemm: out_qk8 goes with the bias epilogue of the split kernels only");
+}
+
 // split fp16 (AACLIP_F16X2): the default kernel on split8 operands, 4 (3: W exact in fp16) virtual tiles per K-tile pair
 template <int NP>
 static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
@@ -1417,6 +1678,15 @@ void read_gemm_stamps(double* out6, int nwaves) {
 #endif  // AACLIP_MEASURE
 
 void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int overlapped) {
+  if (overlapped == 15 && dtype != AACLIP_F16X2 && ((p.K >> 6) & 1) != 0) overlapped = 13;   // odd K-tile count: the one-set 8-wave kernel
+  if (overlapped == 15) {   // the half-tile kernel (256 x 128, two workgroups per CU)
+    if (dtype == AACLIP_F16X2) {
+      if (p.w_exact16) launch_h<f16, 3>(epi, p, s);
+      else launch_h<f16, 4>(epi, p, s);
+    } else if (dtype == AACLIP_F16) launch_h<f16, 0>(epi, p, s);
+    else launch_h<bf16, 0>(epi, p, s);
+    return;
+  }
   if (dtype == AACLIP_F16X2) {
     if (p.w_exact16) launch_split<3>(epi, p, s);
     else launch_split<4>(epi, p, s);

@@ -178,7 +178,7 @@ def test_full_b4_encode_image_taps_vs_reference_golden(dev, g4, weights, code):
 
 # plain fp16 on the outlier record: recorded, asserted only at a loose measured level (it is outside the north star on
 # the plain record already); (per-level / summed maps, taps + pooled)
-OUTLIER_FP16_TOL = ((2e-2, 2e-2), (3e-2, 2e-2), (2e-2, 2e-2))
+OUTLIER_FP16_TOL = (MAP_TOL[F16][0], MAP_TOL[F16][1], TAP_TOL[F16])   # measured: maps 8e-4 / 1.7e-3, taps 2.3e-3 (1.6x the north star)
 
 
 @pytest.mark.parametrize("code", [F32, F16X2, F16])

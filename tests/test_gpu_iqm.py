@@ -285,6 +285,7 @@ def test_iqm_five_tap_levels_take_the_projected_form(dev):
     cfg = synth.tiny_cfg()
     outs = {}
     for precision in ("fp32", "fp16"):
+        torch.manual_seed(4)      # the constructors draw the 1-D parameters: same state for both towers
         clip = CLIP(768, dict(image_size=70, layers=5, width=1024, patch_size=14),
                     dict(context_length=77, vocab_size=cfg.vocab_size, width=cfg.text.width, heads=cfg.text.heads,
                          layers=cfg.text.layers), precision=precision)

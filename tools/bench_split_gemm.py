@@ -8,7 +8,8 @@ import torch
 from aaclip_hip import _lib, engine
 
 def main():
-    exact = "--exact" in sys.argv
+    exact = "--exact" in sys.argv      # (kept for old command lines; the weight format follows the library call)
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     M = 64 * 1370
@@ -25,17 +26,31 @@ def main():
         def run():
             _lib.check(lib.aaclip_gemm(_lib.F16X2, epi, A.data_ptr(), 2 * K, W.data_ptr(), bias.data_ptr(), out.data_ptr(), ldc,
                                        M, N, K, 0, 0, 1.0, st), "gemm")
-        for _ in range(3):
+        first = None
+        for v in variants:
+            assert lib.aaclip_set_gemm_variant(v) == 0, v
+            if epi == 2:
+                out.zero_()
             run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        print(f"{name:9s} K={K} N={N}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s algorithmic", flush=True)
+            torch.cuda.synchronize()
+            got = out.clone()
+            if first is None:
+                first = got
+            else:   # every 256-family kernel computes the same sums in the same order: bit-identical outputs
+                same = torch.equal(got, first)
+                print(f"{name}: variant {v} vs {variants[0]}: {'bit-identical' if same else 'DIFFERENT'}", flush=True)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(f"{name:9s} K={K} N={N} variant {v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s algorithmic", flush=True)
+        lib.aaclip_set_gemm_variant(0)
 
 if __name__ == "__main__":
     main()
