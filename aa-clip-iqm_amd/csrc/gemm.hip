@@ -403,8 +403,17 @@ void set_tail_peel(int v) { g_tail_peel = v; }
 // 0 automatic, 1 force the 128-tile kernel, 80 / 81 force the 8-wave 256 x 256 kernel / the 4-wave 256 x 128 half-tile kernel
 // where 0 would take the other one (both compute bit-identical results); more in the measurement library only
 static int g_gemm_variant = 0;
-static constexpr int DEFAULT_256 = 14;   // launch_gemm256t kernel id of variant 0: 14 = 8 waves, 256 x 256; 15 = half tiles
-static int big_kernel_id() { return g_gemm_variant == 80 ? 14 : (g_gemm_variant == 81 ? 15 : DEFAULT_256); }
+// launch_gemm256t kernel id: 14 = 8 waves, 256 x 256 tile; 15 = 4 waves, 256 x 128 half tile, two workgroups per CU.
+// Measured (profiles/r04_gemm_half_tile_ab.txt): the half tile's K loop is 6-12 % slower (12 instead of 8 DMA
+// pieces per 64 MFMAs on a loop that is bound by exactly that); the overlap of one workgroup's epilogue with the other's K
+// loop wins it back only on isolated epilogue-heavy 16-bit products (out_proj +9...12 %, seg / det projections +10 %) and
+// not inside the tower, where the same products carry the LayerNorm-folding epilogue (tower: 917 vs 923 images/s with
+// them on the half tile, 878 with every product on it); split operands lose 2-8 % on every shape.  So the automatic
+// choice is the 8-wave kernel everywhere and the half tile stays selectable (variant 81).
+static int big_kernel_id(int dtype, const GemmParams& p) {
+  (void)dtype; (void)p;
+  return g_gemm_variant == 81 ? 15 : 14;
+}
 
 static thread_local const char* g_launch_err = nullptr;
 void set_launch_error(const char* msg) { if (!g_launch_err) g_launch_err = msg; }
@@ -455,7 +464,7 @@ static void launch_gemm_big(int dtype, int epi, const GemmParams& p, hipStream_t
     return;
   }
 #endif
-  launch_gemm256t(dtype, epi, p, s, big_kernel_id());
+  launch_gemm256t(dtype, epi, p, s, big_kernel_id(dtype, p));
 }
 
 // True when launch_gemm will run one of the 16x16x32 256-tile kernels (gemm256t.hip) on the whole problem:
@@ -474,7 +483,7 @@ bool gemm_split_routes_to_256t(const GemmParams& p) { return g_gemm_variant != 1
 void launch_gemm(int dtype, int epi, const GemmParams& p, hipStream_t s) {
   if (dtype == AACLIP_F16X2) {   // split fp16: the default 256-tile kernel from M = 4096 rows, else the 128-tile kernel
     if (gemm_split_routes_to_256t(p)) {
-      launch_gemm256t(dtype, epi, p, s, big_kernel_id());
+      launch_gemm256t(dtype, epi, p, s, big_kernel_id(dtype, p));
       return;
     }
     if (p.out_qk8) { set_launch_error("gemm: out_qk8 needs the 256-tile kernel"); return; }

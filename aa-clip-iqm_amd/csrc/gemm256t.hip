@@ -12,6 +12,7 @@
 //     as for the 32x32x16 one (tools/lds_bank_model.py).
 // Operand roles are swapped as in the other kernel (W rows = MFMA A operand), so a
 // lane holds output column m = lane&15 and rows n = 4*(lane>>4) + j of each 16x16 tile.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
@@ -1475,14 +1476,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_256h_kernel(GemmParams p, int P
       KTILE(kt + 2, fnX, fnY, 1)
       KTILE(kt + 3, fnY, fnX, 2)
     }
-  } else {                                 // weight exact in fp16: fp16, fp16, Al8.Wh8; two periods per trip
-    for (int kt = 0; kt < nk; kt += 6) {
+  } else {                                 // weight exact in fp16: fp16, fp16, Al8.Wh8
+    // One period (3 tiles) per trip: the N-side sets have swapped roles after an odd number of tiles, so B0 of the next
+    // tile is moved back into fnX (16 v_mov per 3 tiles); the A stage parity is then a run-time value.  (Two periods per
+    // trip with literal roles, as in the 8-wave kernel, spilled 9-10 registers here.)
+#pragma unroll 1
+    for (int kt = 0; kt < nk; kt += 3) {
       KTILE(kt, fnX, fnY, 0)
       KTILE(kt + 1, fnY, fnX, 0)
       KTILE(kt + 2, fnX, fnY, 1)
-      KTILE(kt + 3, fnY, fnX, 0)
-      KTILE(kt + 4, fnX, fnY, 0)
-      KTILE(kt + 5, fnY, fnX, 1)
+      fnX[0] = fnY[0];
+      fnX[1] = fnY[1];
     }
   }
 #undef DMA
@@ -1530,11 +1534,25 @@ static void launch_h(int epi, const GemmParams& p, hipStream_t s) {
 }
 
 // split fp16 (AACLIP_F16X2): the default kernel on split8 operands, 4 (3: W exact in fp16) virtual tiles per K-tile pair
+// XCD patch shape of the 8-wave kernels: PM x PN tiles of one patch run together on one XCD (32 CUs).  8 x 4 by default;
+// AACLIP_GEMM_PATCH="pm,pn" overrides it for the traffic experiment of profiles/r04_cfc_patch_shapes.txt (a patch
+// column re-reads the A rows once per XCD, a patch row the W rows).  Read once per process; pn must divide N / 256.
+static void patch_shape(int tiles_n, int& PMx, int& PN) {
+  PN = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0) ? 3 : (tiles_n % 2 == 0) ? 2 : 1;
+  PMx = 8;
+  static const char* env = getenv("AACLIP_GEMM_PATCH");
+  if (env) {
+    int pm = 0, pn = 0;
+    if (sscanf(env, "%d,%d", &pm, &pn) == 2 && pm >= 1 && pn >= 1 && tiles_n % pn == 0) { PMx = pm; PN = pn; }
+  }
+}
+
 template <int NP>
 static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
   const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
-  const int PN = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0) ? 3 : (tiles_n % 2 == 0) ? 2 : 1;
-  const int patches_n = tiles_n / PN, PMx = 8;
+  int PN, PMx;
+  patch_shape(tiles_n, PMx, PN);
+  const int patches_n = tiles_n / PN;
   const int pm_x = (tiles_m + PMx - 1) / PMx;
   const int total_x = patches_n * pm_x;
   dim3 gx(((total_x + 7) / 8) * 8 * PMx * PN), b(512);

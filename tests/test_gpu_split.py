@@ -323,3 +323,109 @@ def test_block_long_rows_take_the_e4m3_attention_form(dev, shape):
     assert_close(outs["qk8"], ref, 4e-4, 5e-4, "e4m3 attention form vs fp64")
     assert_close(outs["split16"], ref, 4e-4, 5e-4, "split16 attention form vs fp64")
     assert e8 < 0.25 * ef and e16 < 0.25 * ef
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the two 256-row-tile GEMM kernels (8 waves, 256 x 256 / 4 waves, 256 x 128, two workgroups per CU) compute the same sums
+# in the same order: every output must be BIT-identical between aaclip_set_gemm_variant(80) and (81)
+# ------------------------------------------------------------------------------------------------------------------
+def _variant(lib, v):
+    assert lib.aaclip_set_gemm_variant(v) == 0, v
+
+
+@pytest.mark.parametrize("shape", [(4300, 256, 128), (5480, 1024, 1024), (4097, 768, 384), (6000, 512, 2048)])
+def test_gemm_half_tile_kernel_is_bit_identical_split(dev, shape):
+    lib = _lib.load()
+    M, N, K = shape
+    A = synth.randn("t.h.a", (M, K), 1.0, 4)
+    W = synth.randn("t.h.w", (N, K), K ** -0.5, 4)
+    bias = synth.randn("t.h.b", (N,), 0.5, 4).to(dev)
+    Ad, Wd = engine.split_rows(A.to(dev)), engine.split_rows(W.to(dev), weight=True)
+    x0 = synth.randn("t.h.x", (M, N), 2.0, 4)
+    res = {}
+    try:
+        for v in (80, 81):
+            _variant(lib, v)
+            outs = []
+            o16 = torch.full((M + 2, 4 * N), 0xAA, dtype=torch.uint8, device=dev)
+            _gemm(lib, dev, _lib.EPI_BIAS, Ad, Wd, bias, o16[:M], K, scale_cols=64, scale=0.125)
+            outs.append(o16.clone())
+            _gemm(lib, dev, _lib.EPI_BIAS_GELU, Ad, Wd, bias, o16[:M], K)
+            outs.append(o16.clone())
+            xd = x0.to(dev)
+            _gemm(lib, dev, _lib.EPI_BIAS_RESID, Ad, Wd, bias, xd, K)
+            outs.append(xd)
+            o32 = torch.full((M + 2, N), 7.5, dtype=torch.float32, device=dev)
+            _gemm(lib, dev, _lib.EPI_ACT_F32, Ad, Wd, None, o32[:M], K, act=1)
+            outs.append(o32)
+            res[v] = outs
+    finally:
+        _variant(lib, 0)
+    for a, b, what in zip(res[80], res[81], ("bias", "gelu", "resid", "leaky")):
+        assert torch.equal(a, b), f"{what} {shape}: the half-tile kernel differs from the 8-wave kernel"
+    assert bool((res[81][3][M:] == 7.5).all()) and bool((res[81][0][M:] == 0xAA).all())     # rows past M untouched
+    assert_close(res[81][3][:M], O.leaky_relu(A.double() @ W.double().t()), 3e-4, 1e-4, f"half-tile leaky {shape}")
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_gemm_half_tile_kernel_is_bit_identical_plain(dev, dtype):
+    lib = _lib.load()
+    code = {"fp16": F16, "bf16": _lib.BF16}[dtype]
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    for M, N, K in [(4300, 256, 128), (5480, 1024, 1024), (4500, 768, 3072), (4097, 3072, 768)]:
+        A = synth.randn("t.hp.a", (M, K), 1.0, 4).to(dev).to(tdt)
+        W = synth.randn("t.hp.w", (N, K), K ** -0.5, 4).to(dev).to(tdt)
+        bias = synth.randn("t.hp.b", (N,), 0.5, 4).to(dev)
+        x0 = synth.randn("t.hp.x", (M, N), 2.0, 4)
+        res = {}
+        try:
+            for v in (80, 81):
+                _variant(lib, v)
+                outs = []
+                for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU):
+                    o = torch.zeros(M, N, dtype=tdt, device=dev)
+                    _lib.check(lib.aaclip_gemm(code, epi, A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), o.data_ptr(), N,
+                                               M, N, K, 0, 64, 0.125, stream(dev)), "gemm")
+                    outs.append(o)
+                xd = x0.to(dev)
+                _lib.check(lib.aaclip_gemm(code, _lib.EPI_BIAS_RESID, A.data_ptr(), K, W.data_ptr(), bias.data_ptr(),
+                                           xd.data_ptr(), N, M, N, K, 0, 0, 1.0, stream(dev)), "gemm")
+                outs.append(xd)
+                res[v] = outs
+        finally:
+            _variant(lib, 0)
+        for a, b in zip(res[80], res[81]):
+            assert torch.equal(a, b), f"{dtype} {(M, N, K)}: the half-tile kernel differs from the 8-wave kernel"
+        ref = x0.double() + A.double().cpu() @ W.double().cpu().t() + bias.double().cpu()
+        assert_close(res[81][2], ref, 2e-2 if dtype == "bf16" else 4e-3, 1e-2, f"half-tile resid {dtype}")
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_blocks_half_tile_kernel_is_bit_identical(dev, exact):
+    """Two full-size blocks through aaclip_blocks (B = 4: M = 5480 rows, the 256-row-tile regime) in fp16x2, with the
+    weights as drawn (4 virtual tiles per K pair) and rounded through fp16 (3 tiles; the QKV product writes the attention
+    kernel's e4m3 records in both): the stream after the blocks is bit-identical under both GEMM kernels."""
+    from model.clip import create_model
+    lib = _lib.load()
+    cfg = synth.ClipCfg()
+    sd = synth.synth_clip_state_dict(cfg, 111)
+    if exact:
+        sd = {k: (v.half().float() if v.is_floating_point() else v) for k, v in sd.items()}
+    clip = create_model("ViT-L-14-336", 518, pretrained=None, precision="fp16x2", force_image_size=518)
+    clip.load_state_dict(sd, strict=True)
+    clip = clip.to(dev).eval()
+    B, L = 4, 1370
+    x0 = synth.randn("t.hb.x", (B * L, 1024), 1.0, 5).to(dev)
+    blocks = list(clip.visual.transformer.resblocks)[:2]
+    res = {}
+    try:
+        for v in (80, 81):
+            _variant(lib, v)
+            x = x0.clone()
+            with torch.no_grad():
+                engine.run_blocks(x, blocks, B, L, 16, F16X2)
+            res[v] = x
+    finally:
+        _variant(lib, 0)
+    assert torch.isfinite(res[80]).all() and float((res[80] - x0).abs().max()) > 0.1
+    assert torch.equal(res[80], res[81])

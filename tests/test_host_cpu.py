@@ -314,6 +314,19 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
         assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi} NP {np_}: spill in the K loop"
         checked += 1
     assert checked == 17
+    # the half-tile kernel (4 waves, 256 x 128): the same two properties for every instantiation the launcher can reach
+    for epi, np_, qk8 in [(e, n, 0) for n in (0, 4, 3) for e in range(5)] + [(0, 4, 1), (0, 3, 1)]:
+        sym = f"_ZN6aaclip18gemm16_256h_kernelIDF16_Li{epi}ELi{np_}ELb{qk8}EEEvNS_10GemmParamsEiiiii:"
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
+        body = lines[start:end]
+        first_store = next(i for i, l in enumerate(body) if "global_store" in l or "buffer_store" in l)
+        bars = [i for i, l in enumerate(body[:first_store]) if "s_barrier" in l]
+        loop = [l.split()[0] for l in body[bars[0]:bars[-1]] if l.strip() and not l.strip().startswith((".", ";"))]
+        assert loop.count("buffer_load_dwordx4") >= 12, (epi, np_, "K loop not found")
+        assert "v_readfirstlane_b32" not in loop and "s_and_saveexec_b64" not in loop, \
+            f"half tile, EPI {epi} NP {np_}: waterfall loop around the K-loop DMA"
+        assert not any(op.startswith("scratch_") for op in loop), f"half tile, EPI {epi} NP {np_}: spill in the K loop"
 
 
 def test_tower_run_plans_one_call_with_tap_buffers(monkeypatch):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Times the split-fp16 (AACLIP_F16X2) GEMM kernel on the tower's four shapes: ms per launch and algorithmic TFLOP/s.
+Environment: VARIANTS=80,81 (kernel A/B with a bit-identity check), ONLY=c_fc,qkv (subset of the shapes).
 AACLIP_LIB selects an experiment build of the library.  python tools/bench_split_gemm.py [--exact]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,8 +15,11 @@ def main():
     dev = torch.device("cuda:0")
     M = 64 * 1370
     st = torch.cuda.current_stream(dev).cuda_stream
+    only = os.environ.get("ONLY", "")
     for name, (K, N, epi) in {"qkv": (1024, 3072, 0), "out_proj": (1024, 1024, 2), "c_fc": (1024, 4096, 1),
                               "c_proj": (4096, 1024, 2)}.items():
+        if only and name not in only.split(","):
+            continue
         A = torch.randint(0, 255, (M, 4 * K), dtype=torch.uint8, device=dev)
         A[:, 1::2][:, :K] &= 0x3B          # keep the fp16 plane's exponents moderate (finite values)
         W = torch.randint(0, 255, (N, 4 * K), dtype=torch.uint8, device=dev)
