@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void skel(const char* A, const char* 
 }
 
 static char* dA; static char* dW; static float* dOut;
-static const int LD = 2048;          // K = 1024 halves per row
+static int LD = 2048;                // row stride in bytes: K = 1024 halves per row (argv[1] overrides: a padded stride)
 static const int NPANELS = 2048;     // 2048 x 256 rows x 2 KiB = 1 GiB of A
 static double bare_tf[2] = {0, 0};
 
@@ -164,7 +164,9 @@ void run(const char* what, int wgs_per_cu, int bare_slot = -1, int npanels = NPA
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) LD = atoi(argv[1]);
+  printf("row stride %d bytes\n", LD);
   const size_t abytes = (size_t)NPANELS * 256 * LD;
   hipMalloc(&dA, abytes + (1 << 20));
   hipMalloc(&dW, (size_t)256 * LD + (1 << 20));
