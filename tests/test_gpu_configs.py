@@ -293,15 +293,15 @@ def test_config5_b128_four_tap_layers(dev, g4, weights, code):
         compare("bf16.b128.seg3_first4", a, b, 1e-2, 5e-2)
 
 
-def test_fp16x2_keeps_the_north_star_on_another_seed(dev):
+@pytest.mark.parametrize("seed", [1017, 4242])
+def test_fp16x2_keeps_the_north_star_on_another_seed(dev, seed):
     """The golden record is ONE set of weights and images.  A second one (other synthetic weights, fp16-exact like
     OpenAI's, other images; no reference numbers exist for it: "parity unpinned", the exact-fp32 mode of this build --
     0.006 of the bound on the golden record -- stands in): fp16x2 must keep taps, pooled embedding, seg / det tokens and
     per-level pre-blur maps inside 1e-3 + 1e-2 |ref| there as well (measured over six seeds: 0.44-0.48 of the bound,
-    tools/margin_probe.py)."""
+    tools/margin_probe.py; the second seed promotes that probe into the suite)."""
     import forward_utils as FU
     cfg = synth.ClipCfg()
-    seed = 1017
     sd = {k: (v.half().float() if v.is_floating_point() else v) for k, v in synth.synth_clip_state_dict(cfg, seed).items()}
     w = (cfg, sd, synth.synth_image_adapter_state_dict(cfg, seed=seed), synth.synth_text_adapter_state_dict(cfg, seed=seed))
     img = synth.synth_images(4, 518, seed=seed).to(dev)
