@@ -14,11 +14,12 @@ ap.add_argument("--variants", default="0,131072")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--precision", default="fp16")
 a = ap.parse_args()
 lib = _lib.load()
 dev = torch.device("cuda:0")
 cfg = synth.ClipCfg()
-clip = create_model("ViT-L-14-336", 518, pretrained=None, precision="fp16", force_image_size=518)
+clip = create_model("ViT-L-14-336", 518, pretrained=None, precision=a.precision, force_image_size=518)
 clip.load_state_dict(synth.synth_clip_state_dict(cfg, 111), strict=True)
 clip = clip.to(dev).eval()
 gen = torch.Generator(device=dev).manual_seed(5)
