@@ -480,9 +480,15 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
   }
 
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last P.V MFMAs (inline asm) have written o before VALU reads it
-  if (qi < L) {
+  // Epilogue (round 4): a lane holds 4-value groups of ONE query row, so storing straight from the accumulator layout is
+  // 24 instructions per wave of 4 or 8 scattered bytes per lane (16 bytes per row and instruction); skipping a quarter of
+  // them (the hi8 plane) was worth 6.5 % of the kernel, which priced the whole tail at ~20 %.  The rows go through the
+  // (now idle) LDS instead: per wave 32 rows x [hi 128 B | lo8 64 B | hi8 64 B] at a 272-byte stride, read back as 16-byte
+  // chunks so that one store instruction covers 4 rows with whole 128- / 64-byte segments (8 instructions per wave).
+  {
     const float inv = 1.0f / l;
-    f16* dst = ctx + ((long)b * L + qi) * 2 * D + head * 64;
+    char* st = smem + wave * (32 * 272);
+    char* srow = st + r * 272;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -493,11 +499,22 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
         uint32_t l8, h8;
         split8x4_sat(vv, vh, l8, h8);
         const int col = db * 32 + 8 * gi + 4 * h;
-        *(vec4*)(dst + col) = vh;
-        uint8_t* p8 = (uint8_t*)(dst - head * 64 + D) + head * 64;   // e4m3 planes of this row: lo8 at 2D bytes, hi8 at 3D
-        *(uint32_t*)(p8 + col) = l8;
-        if (hi8) *(uint32_t*)(p8 + D + col) = h8;
+        *(vec4*)(srow + col * 2) = vh;
+        *(uint32_t*)(srow + 128 + col) = l8;
+        *(uint32_t*)(srow + 192 + col) = h8;
       }
+    char* cbase = (char*)ctx + ((long)b * L + q0) * 4 * D;
+    const int chunk = lane & 15;
+    // byte offset of this lane's chunk inside its row: hi plane | lo8 plane (2D) | hi8 plane (3D)
+    const int coff = chunk < 8 ? head * 128 + chunk * 16
+                               : (chunk < 12 ? 2 * D + head * 64 + (chunk - 8) * 16 : 3 * D + head * 64 + (chunk - 12) * 16);
+    const bool live_chunk = hi8 || chunk < 12;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const u32x4 v = *(const u32x4*)(st + row * 272 + chunk * 16);
+      if (live_chunk && q0 + row < L) *(u32x4*)(cbase + (long)row * 4 * D + coff) = v;
+    }
   }
 }
 
