@@ -1045,6 +1045,13 @@ AACLIP_DEV f32x4 mma_e4m3k(const FragPair<f16, true>& w, const FragPair<f16, tru
 }
 template <int KIND, typename T> AACLIP_DEV f32x4 mma_e4m3k(const FragPair<T, false>&, const FragPair<T, false>&, f32x4 c, int) { return c; }
 
+// X_PRIO_MODE (build-time switch): 0 = s_setprio 1 around every MFMA cluster (rounds 1-3), 1 = static priority for waves
+// 4-7 and no per-segment flips (MI355X_MICROARCH.md, "Two waves per SIMD", item 4), 2 = no priorities at all.  Measured in
+// round 4 on one box, three builds side by side: split products -1.1 ... -1.7 % with 1 or 2, tower 516 -> 520.5 images/s
+// with either, plain fp16 within noise.  Default 2: the per-segment flips were costing what the guide says they cost.
+#ifndef X_PRIO_MODE
+#define X_PRIO_MODE 2
+#endif
 template <typename T, int EPI, int NP = 0, bool QK8 = false>   // QK8: GemmParams::out_qk8 (EPI_BIAS, split operands only)
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
@@ -1174,7 +1181,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   {                                                                                          \
     LGKM0                                                                                    \
     PINB                                                                                     \
-    __builtin_amdgcn_s_setprio(1);                                                           \
+    if (X_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);                                     \
     if ((KIND) != 0) {                                                                       \
       MM8(FN, a, b, 0, 0, KIND) MM8(FN, a, b, 0, 1, KIND) MM8(FN, a, b, 1, 0, KIND) MM8(FN, a, b, 1, 1, KIND) \
       MM8(FN, a, b, 2, 0, KIND) MM8(FN, a, b, 2, 1, KIND) MM8(FN, a, b, 3, 0, KIND) MM8(FN, a, b, 3, 1, KIND) \
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     MM(FN, a, b, 0, 0, 1) MM(FN, a, b, 0, 1, 1) MM(FN, a, b, 1, 0, 1) MM(FN, a, b, 1, 1, 1)  \
     MM(FN, a, b, 2, 0, 1) MM(FN, a, b, 2, 1, 1) MM(FN, a, b, 3, 0, 1) MM(FN, a, b, 3, 1, 1)  \
     }                                                                                        \
-    __builtin_amdgcn_s_setprio(0);                                                           \
+    if (X_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);                                     \
     PINB                                                                                     \
   }
 // one K tile: FB0 holds B0(kt) on entry; FB1 receives B1(kt) and then B0(kt+1)
@@ -1231,6 +1238,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   BAR
   LD_N(fnX, smem, 0)
   if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
+  if (X_PRIO_MODE == 1 && wr == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half, no flips
   if constexpr (NP == 0) {
     for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
       KTILE(kt, fnX, fnY, 0)
