@@ -1052,6 +1052,11 @@ template <int KIND, typename T> AACLIP_DEV f32x4 mma_e4m3k(const FragPair<T, fal
 #ifndef X_PRIO_MODE
 #define X_PRIO_MODE 2
 #endif
+// X_LOAD_ORDER (build-time experiment switch) of a LOAD segment: 0 = counted wait, fragment reads, DMA issue; 1 = DMA issue
+// before the reads; 2 = the counted wait LAST (two more instructions outstanding: the same piece confirmed a segment later)
+#ifndef X_LOAD_ORDER
+#define X_LOAD_ORDER 0
+#endif
 template <typename T, int EPI, int NP = 0, bool QK8 = false>   // QK8: GemmParams::out_qk8 (EPI_BIAS, split operands only)
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
   typedef typename Elem<T>::vec8 vec8;
@@ -1201,30 +1206,38 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     const bool more1 = (kt) + 1 < nk, more2 = (kt) + 2 < nk;                                  \
     const char* sb = smem + cur * 65536;                                                      \
     /* P0: confirm B1(kt); read A0(kt); issue A0(kt+1) */                                     \
-    if (more1) WAIT_VM(4); else WAIT_VM(2);                                                   \
+    if (X_LOAD_ORDER != 2) { if (more1) WAIT_VM(4); else WAIT_VM(2); }                        \
+    if (X_LOAD_ORDER == 1 && more1) GA(0, nxt, (kt) + 1)                                      \
     LD_M(sb, 0)                                                                               \
-    if (more1) GA(0, nxt, (kt) + 1)                                                           \
+    if (X_LOAD_ORDER != 1 && more1) GA(0, nxt, (kt) + 1)                                      \
+    if (X_LOAD_ORDER == 2) { if (more1) WAIT_VM(6); else WAIT_VM(2); }                        \
     BAR                                                                                       \
     QUADX(FB0, 0, 0, KIND)                                                                          \
     BAR                                                                                       \
     /* P1: confirm A1(kt); read B1(kt); issue B1(kt+1) */                                     \
-    if (more1) WAIT_VM(4); else WAIT_VM(0);                                                   \
+    if (X_LOAD_ORDER != 2) { if (more1) WAIT_VM(4); else WAIT_VM(0); }                        \
+    if (X_LOAD_ORDER == 1 && more1) GW(1, nxt, (kt) + 1)                                      \
     LD_N(FB1, sb, 1)                                                                          \
-    if (more1) GW(1, nxt, (kt) + 1)                                                           \
+    if (X_LOAD_ORDER != 1 && more1) GW(1, nxt, (kt) + 1)                                      \
+    if (X_LOAD_ORDER == 2) { if (more1) WAIT_VM(6); else WAIT_VM(0); }                        \
     BAR                                                                                       \
     QUADX(FB1, 0, 1, KIND)                                                                          \
     BAR                                                                                       \
     /* P2: confirm B0(kt+1); read A1(kt); issue A1(kt+1) */                                   \
-    if (more1) WAIT_VM(4);                                                                    \
+    if (X_LOAD_ORDER != 2 && more1) WAIT_VM(4);                                               \
+    if (X_LOAD_ORDER == 1 && more1) GA(1, nxt, (kt) + 1)                                      \
     LD_M(sb, 1)                                                                               \
-    if (more1) GA(1, nxt, (kt) + 1)                                                           \
+    if (X_LOAD_ORDER != 1 && more1) GA(1, nxt, (kt) + 1)                                      \
+    if (X_LOAD_ORDER == 2 && more1) WAIT_VM(6);                                               \
     BAR                                                                                       \
     QUADX(FB1, 1, 1, KIND)                                                                          \
     BAR                                                                                       \
     /* P3: confirm A0(kt+1); read B0(kt+1) into the set B1 vacated; issue B0(kt+2) */         \
-    if (more1) WAIT_VM(4);                                                                    \
+    if (X_LOAD_ORDER != 2 && more1) WAIT_VM(4);                                               \
+    if (X_LOAD_ORDER == 1 && more2) GW(0, cur, (kt) + 2)                                      \
     if (more1) LD_N(FB1, smem + nxt * 65536, 0)                                               \
-    if (more2) GW(0, cur, (kt) + 2)                                                           \
+    if (X_LOAD_ORDER != 1 && more2) GW(0, cur, (kt) + 2)                                      \
+    if (X_LOAD_ORDER == 2 && more1) { if (more2) WAIT_VM(6); else WAIT_VM(4); }               \
     BAR                                                                                       \
     QUADX(FB0, 1, 0, KIND)                                                                          \
     BAR                                                                                       \
