@@ -1250,7 +1250,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
   BAR
   LD_N(fnX, smem, 0)
+#ifndef X_NO_STAGGER
   if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
+#endif
   if (X_PRIO_MODE == 1 && wr == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half, no flips
   if constexpr (NP == 0) {
     for (int kt = 0; kt < nk; kt += 2) {   // nk is even (checked by the launcher)
@@ -1274,7 +1276,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
       KTILE(kt + 5, fnY, fnX, 1)
     }
   }
+#ifndef X_NO_STAGGER
   if (wr == 0) BAR   // balance the barrier count of the two groups
+#endif
 #undef DMA
 #undef GA
 #undef GW
