@@ -409,6 +409,14 @@ def run_rank(args):
                         extra["fp16x2_fp16_exact_clip_weights"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                     finally:
                         args.clip_weights = "fp32"
+        # parity of the timed model, measured now (rank 0; the other ranks wait in the barrier below, so that no rank tears
+        # the process group down while rank 0 still works)
+        parity = None
+        if rank == 0 and not rehearse:
+            try:
+                parity = parity_in_run(clip, model, args.precision, args.clip_weights, dev, torch)
+            except Exception as e:   # noqa: BLE001
+                parity = {"error": f"{type(e).__name__}: {e}"[:300]}
         if dist is not None:
             dist.barrier()
 
@@ -486,7 +494,7 @@ def run_rank(args):
                     "flop_per_launch": fc_flop,
                     "mfma_time_multiple": (1.5 if args.clip_weights == "fp16" else 2.0) if args.precision == "fp16x2" else 1.0,
                 },
-                "parity_vs_north_star": parity_in_run(clip, model, args.precision, args.clip_weights, dev, torch),
+                "parity_vs_north_star": parity,
             })
         result.update(extra)
         if n_gpus == 1 and not args.no_extra and not rehearse:
