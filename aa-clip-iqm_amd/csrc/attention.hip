@@ -325,18 +325,45 @@ __global__ __launch_bounds__(256, VL ? 2 : 3) void attn16s_kernel(const f16* __r
   if (last_q > L - 1) last_q = L - 1;
   const int nkt = causal ? (last_q / 64 + 1) : ((L + 63) / 64);
 
+  // K / V pieces as buffer_load ... lds (round 4): per-lane 32-bit offsets fixed for the whole kernel, the tile advance in
+  // the SCALAR offset -- no 64-bit VALU address arithmetic per piece (~26 VALU instructions per tile before).  The base
+  // goes through unsigned halves: readfirstlane returns int, and OR-ing a negative low half into the 64-bit value
+  // sign-extends it (a descriptor base of 0xffff... whenever bit 31 of the address is set: the intermittent fault of the
+  // first version of this change).  Rows past the end of the image re-read row L-1 (their keys are masked): per-lane
+  // arithmetic only in the one tile that has them.
+  int kvo[2], vvo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    kvo[j] = (int)((ksrc[j] - base) * 2);
+    vvo[j] = (int)((vsrc[j] - base) * 2);
+  }
+  __amdgpu_buffer_rsrc_t rs;
+  {
+    const unsigned long long ub = (unsigned long long)base;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32));
+    const f16* ubase = (const f16*)(((unsigned long long)bhi << 32) | (unsigned long long)blo);
+    const int nrec = __builtin_amdgcn_readfirstlane((int)(((long)L * ld - head * 64) * 2));   // this image, from `base` on
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)ubase, 0, nrec, 0x00020000);
+  }
+  const int ldb = __builtin_amdgcn_readfirstlane((int)(64 * ld * 2));
   auto stage = [&](int st, int kt) {
     char* dst = smem + st * STAGE + wave * 2048;
-    const long step = (long)kt * 64 * ld;
+    const int so = kt * ldb;
+    const bool tail = kt * 64 + 63 > L - 1;   // wave-uniform: only the last tile of a row of keys has rows past the end
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int over = kt * 64 + drow[j] - (L - 1);
-      over = over > 0 ? over : 0;   // rows past the end re-read row L-1 (masked later)
-      const long so = step - (long)over * ld;
-      glds16(ksrc[j] + so, dst + j * 1024);
-      glds16(vsrc[j] + so, dst + 8192 + j * 1024);
-      glds16(ksrc[j] + so + LO, dst + 16384 + j * 1024);
-      if (VL) glds16(vsrc[j] + so + LO, dst + 24576 + j * 1024);
+      int ko = kvo[j], vo = vvo[j];
+      if (tail) {
+        int over = kt * 64 + drow[j] - (L - 1);
+        over = over > 0 ? over : 0;
+        ko -= over * (int)ld * 2;
+        vo -= over * (int)ld * 2;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + j * 1024), 16, ko, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 8192 + j * 1024), 16, vo, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 16384 + j * 1024), 16, ko, so + LO * 2, 0, 0);
+      if (VL) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 24576 + j * 1024), 16, vo, so + LO * 2, 0, 0);
     }
   };
 
