@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the split-fp16 (AACLIP_F16X2) GEMM kernel on the tower's four shapes: ms per launch and algorithmic TFLOP/s.
-Environment: VARIANTS=80,81 (kernel A/B with a bit-identity check), ONLY=c_fc,qkv (subset of the shapes).
+Environment: VARIANTS=80,81 (kernel A/B with a bit-identity check), ONLY=c_fc,qkv (subset of the shapes), MROWS=<rows>.
 AACLIP_LIB selects an experiment build of the library.  python tools/bench_split_gemm.py [--exact]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ def main():
     variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    M = 64 * 1370
+    M = int(os.environ.get("MROWS", 64 * 1370))     # MROWS=81920: 320 row tiles, every shape an exact number of rounds
     st = torch.cuda.current_stream(dev).cuda_stream
     only = os.environ.get("ONLY", "")
     for name, (K, N, epi) in {"qkv": (1024, 3072, 0), "out_proj": (1024, 1024, 2), "c_fc": (1024, 4096, 1),
