@@ -106,10 +106,10 @@ int aaclip_set_gemm_variant(int v) {
   // Validate everything before changing anything: a rejected call leaves the selection as it was.
   const int gv = v & 0xFF, av = (v >> 8) & 0xFF;
 #ifdef AACLIP_MEASURE
-  REQUIRE((gv <= 60 || gv == 70 || gv == 80 || gv == 81) && (av <= 3 || av == 6), "set_gemm_variant: no such kernel variant");
+  REQUIRE((gv <= 60 || gv == 70 || (gv >= 80 && gv <= 82)) && (av <= 3 || av == 6), "set_gemm_variant: no such kernel variant");
 #else
-  REQUIRE((gv <= 1 || gv == 80 || gv == 81) && av <= 1,
-          "set_gemm_variant: libaaclip_hip.so only has GEMM variants 0/1/80/81 and attention variants 0/1; A/B variants, "
+  REQUIRE((gv <= 1 || (gv >= 80 && gv <= 82)) && av <= 1,
+          "set_gemm_variant: libaaclip_hip.so only has GEMM variants 0/1/80/81/82 and attention variants 0/1; A/B variants, "
           "timing ablations (wrong results) and stamp builds live in libaaclip_hip_measure.so (make measure)");
 #endif
   set_gemm_variant(gv);

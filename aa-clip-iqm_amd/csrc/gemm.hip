@@ -400,8 +400,8 @@ const char* gemm_check(int dtype, int epi, const GemmParams& p) {
 
 static int g_tail_peel = 0;  // measured: not a win (the 128-tile kernel is too slow for the peeled rows)
 void set_tail_peel(int v) { g_tail_peel = v; }
-// 0 automatic, 1 force the 128-tile kernel, 80 / 81 force the 8-wave 256 x 256 kernel / the 4-wave 256 x 128 half-tile kernel
-// where 0 would take the other one (both compute bit-identical results); more in the measurement library only
+// 0 automatic, 1 force the 128-tile kernel, 80 / 81 / 82 force the 8-wave 256 x 256 kernel (one tile per workgroup) / the
+// 4-wave 256 x 128 half-tile kernel / the walking 8-wave kernel (all bit-identical); more in the measurement library only
 static int g_gemm_variant = 0;
 // launch_gemm256t kernel id: 14 = 8 waves, 256 x 256 tile; 15 = 4 waves, 256 x 128 half tile, two workgroups per CU.
 // Measured (profiles/r04_gemm_half_tile_ab.txt): the half tile's K loop is 6-12 % slower (12 instead of 8 DMA
@@ -410,9 +410,14 @@ static int g_gemm_variant = 0;
 // not inside the tower, where the same products carry the LayerNorm-folding epilogue (tower: 917 vs 923 images/s with
 // them on the half tile, 878 with every product on it); split operands lose 2-8 % on every shape.  So the automatic
 // choice is the 8-wave kernel everywhere and the half tile stays selectable (variant 81).
+// 16 = the 8-wave kernel WALKING its tiles (one workgroup per CU; the next tile's first K tile is fetched under the
+// epilogue of the current one; split operands only, launch_gemm256t falls back to 14 for the others): bit-identical,
+// tower +0.5 % (profiles/r04_gemm_walk_ab.txt).  Automatic for split operands; 80 forces the one-tile-per-workgroup form.
 static int big_kernel_id(int dtype, const GemmParams& p) {
-  (void)dtype; (void)p;
-  return g_gemm_variant == 81 ? 15 : 14;
+  (void)p;
+  if (g_gemm_variant == 81) return 15;
+  if (g_gemm_variant == 80) return 14;
+  return (dtype == AACLIP_F16X2 || g_gemm_variant == 82) ? 16 : 14;
 }
 
 static thread_local const char* g_launch_err = nullptr;
@@ -436,9 +441,9 @@ bool set_gemm_variant(int v) {
 #ifdef AACLIP_MEASURE
   // 2..5 = 256-tile kernels on 32x32x16 MFMAs (gemm256.hip), 6..60 = the 16x16x32 family incl. timing ablations and
   // the stamp build (gemm256t.hip), 70 = persistent tiles (gemm256z.hip)
-  const bool ok = v >= 0 && (v <= 60 || v == 70 || v == 80 || v == 81);
+  const bool ok = v >= 0 && (v <= 60 || v == 70 || v == 80 || v == 81 || v == 82);
 #else
-  const bool ok = v == 0 || v == 1 || v == 80 || v == 81;
+  const bool ok = v == 0 || v == 1 || v == 80 || v == 81 || v == 82;
 #endif
   if (ok) g_gemm_variant = v;
   return ok;

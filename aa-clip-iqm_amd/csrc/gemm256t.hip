@@ -39,9 +39,15 @@ AACLIP_DEV float row16_sum(float x) {
 }
 // acc[mi][ni][j]: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j   (mi 0..7, ni 0..3)
 // NWC = waves along N: 4 for the 256 x 256 tile of 8 waves, 2 for the 256 x 128 half tile of 4 waves (gemm16_256h_kernel)
-template <typename T, int EPI, bool SPLIT = false, bool QK8 = false, int NWC = 4>
+// COMPACT: the staging area of a wave is 8 KiB instead of 16 (split operands only): the walking kernel
+// (gemm16_256x_kernel<..., WALK>) stages in ONE operand stage while the next tile's first pieces land in the other
+template <typename T, int EPI, bool SPLIT = false, bool QK8 = false, int NWC = 4, bool COMPACT = false>
 AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem, int tm, int tn, int wave, int lane,
                              const f32x2* ab_pre = nullptr) {
+  static_assert(!COMPACT || SPLIT, "the compact staging geometry exists for the split-operand epilogues");
+  constexpr int STG = COMPACT ? 8192 : 16384;      // staging bytes per wave
+  constexpr int SROWS = COMPACT ? 31 : 63;         // row mask of a 16-bit staging pass
+  constexpr int SPL = COMPACT ? 4096 : 8192;       // offset of the e4m3 planes (or the lo tile) behind the hi tile
   typedef typename Elem<T>::vec4 vec4;
   // Everything the epilogue addresses with is derived from `lane` below this point: the empty asm keeps hipcc from
   // computing it before the K loop and carrying it through (measured: the folding code alone cost the residual
@@ -52,7 +58,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
   const int m_base = tm * 256 + wr * 128, n_base = tn * (NWC * 64) + wc * 64;
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
     __syncthreads();  // every wave is done reading the operand tiles
-    char* st = smem + wave * 16384;  // this wave's 128 x 64 tile of T: rows of 128 B, 16-B chunk ^= (m & 7)
+    char* st = smem + wave * STG;  // this wave's 128 x 64 tile of T: rows of 128 B, 16-B chunk ^= (m & 7)
     const bool fold = p.row_ab != nullptr;   // LayerNorm folded into this product: acc -> a_m * acc + b_m * s_n
     f32x2 ab[8];
     if (fold) {
@@ -112,12 +118,12 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
               // attention records for the e4m3 correction form (attention.hip, QK8): hi tile as below; the e4m3 planes
               // of this wave's 64 columns (ONE head of q or k) share a 128-byte staging row [lo8 | hi8], which is also
               // the record's layout in memory.  v columns (>= out_qk8) carry no correction.
-              char* sp = st + (m & 63) * 128;
+              char* sp = st + (m & SROWS) * 128;
               if (n_base < p.out_qk8) {   // wave-uniform: this wave's 64 columns are one head of q or of k
                 uint32_t l8, h8;
                 split8x4_sat(vv, o, l8, h8);   // (the split kernels run fp8_saturate_mode() at entry)
-                *(uint32_t*)(sp + 8192 + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
-                *(uint32_t*)(sp + 8192 + (((4 + (nl >> 4)) ^ (m & 7)) << 4) + (nl & 12)) = h8;
+                *(uint32_t*)(sp + SPL + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
+                *(uint32_t*)(sp + SPL + (((4 + (nl >> 4)) ^ (m & 7)) << 4) + (nl & 12)) = h8;
               } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (f16)vv[j];
@@ -134,19 +140,19 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
               o[j] = hi;
               o2[j] = lo;
             }
-            char* sp = st + (m & 63) * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2;
+            char* sp = st + (m & SROWS) * 128 + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2;
             *(vec4*)sp = o;
-            *(vec4*)(sp + 8192) = o2;
+            *(vec4*)(sp + SPL) = o2;
             }
           } else if constexpr (SPLIT) {
             // split8 rows (the next product's A operand): hi tile as above; the e4m3 planes of a row share one
             // 128-byte staging row, [lo8: 64 bytes][hi8: 64 bytes], 16-byte chunks swizzled like the hi tile
             uint32_t l8, h8;
             split8x4_sat(vv, o, l8, h8);   // (the split kernels run fp8_saturate_mode() at entry)
-            char* sp = st + (m & 63) * 128;
+            char* sp = st + (m & SROWS) * 128;
             *(vec4*)(sp + ((((nl >> 3)) ^ (m & 7)) << 4) + (nl & 4) * 2) = o;
-            *(uint32_t*)(sp + 8192 + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
-            *(uint32_t*)(sp + 8192 + (((4 + (nl >> 4)) ^ (m & 7)) << 4) + (nl & 12)) = h8;
+            *(uint32_t*)(sp + SPL + (((nl >> 4) ^ (m & 7)) << 4) + (nl & 12)) = l8;
+            *(uint32_t*)(sp + SPL + (((4 + (nl >> 4)) ^ (m & 7)) << 4) + (nl & 12)) = h8;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = from_float<T>(vv[j]);
@@ -159,9 +165,9 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
         const int m = it * 8 + (lane >> 3), c = lane & 7;
         const int row = m_base + m;
         if constexpr (SPLIT) {
-          const char* sp = st + (m & 63) * 128 + ((c ^ (m & 7)) << 4);
+          const char* sp = st + (m & SROWS) * 128 + ((c ^ (m & 7)) << 4);
           const u32x4 vh = *(const u32x4*)sp;
-          const u32x4 vl = *(const u32x4*)(sp + 8192);
+          const u32x4 vl = *(const u32x4*)(sp + SPL);
           if (row < p.M) {
             T* orow = (T*)p.out + (long)row * p.ldc;
             ST_OUT((u32x4*)(orow + n_base + c * 8), vh);
@@ -188,18 +194,20 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
     // global instruction would touch 64 cache lines for 1 KiB; staged through LDS (64 rows x 256 B per
     // half, 16-B chunk ^= row & 15, conflict-free both ways) one instruction covers 4 rows x 256 B = 8 lines.
     __syncthreads();  // every wave is done reading the operand tiles
-    char* st = smem + wave * 16384;
+    char* st = smem + wave * STG;
+    constexpr int PARTS = COMPACT ? 4 : 2;         // row groups staged one after the other (64 or 32 rows each)
+    constexpr int PIT = 32 / PARTS, PMI = 8 / PARTS;
     const int cc = lane & 15, rr = lane >> 4;      // read-back: chunk (4 columns) and row-in-group of this lane
     const int n0 = n_base + cc * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_BIAS_RESID || (EPI == EPI_ACT_F32 && p.bias)) bv = *(const f32x4*)(p.bias + n0);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      f32x4 extra[16];
-      long orow[16];
+    for (int half = 0; half < PARTS; ++half) {
+      f32x4 extra[PIT];
+      long orow[PIT];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = m_base + half * 64 + it * 4 + rr;
+      for (int it = 0; it < PIT; ++it) {
+        const int row = m_base + half * (4 * PIT) + it * 4 + rr;
         orow[it] = row;
         if (EPI == EPI_PATCH) {
           const int rc = row < p.M ? row : p.M - 1;
@@ -212,14 +220,14 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
         }
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < PMI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int m = mi * 16 + c16;
-          *(f32x4*)(st + m * 256 + (((ni * 4 + q4) ^ (m & 15)) << 4)) = acc[half * 4 + mi][ni];
+          *(f32x4*)(st + m * 256 + (((ni * 4 + q4) ^ (m & 15)) << 4)) = acc[half * PMI + mi][ni];
         }
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
+      for (int it = 0; it < PIT; ++it) {
         const int m = it * 4 + rr;
         f32x4 v = *(const f32x4*)(st + m * 256 + ((cc ^ (m & 15)) << 4));
         if (EPI == EPI_BIAS_RESID) {
@@ -236,7 +244,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
         } else if (EPI == EPI_PATCH) {
           v = v + extra[it];
         }
-        const bool live = m_base + half * 64 + m < p.M;
+        const bool live = m_base + half * (4 * PIT) + m < p.M;
         if (live) ST_OUT((f32x4*)((float*)p.out + orow[it] * p.ldc + n0), v);
         if (EPI == EPI_BIAS_RESID && p.out16) {
           // LayerNorm folding: the next product reads the new residual rows in 16 bits (of THOSE rounded
@@ -1057,8 +1065,14 @@ template <int KIND, typename T> AACLIP_DEV f32x4 mma_e4m3k(const FragPair<T, fal
 #ifndef X_LOAD_ORDER
 #define X_LOAD_ORDER 0
 #endif
-template <typename T, int EPI, int NP = 0, bool QK8 = false>   // QK8: GemmParams::out_qk8 (EPI_BIAS, split operands only)
+// WALK (round 4, split operands only): ONE workgroup per CU walks the tiles b, b + gridDim.x, ... of the same virtual grid
+// (same XCD: gridDim.x is a multiple of 8), and issues the first K tile of its NEXT tile into the free operand stage before
+// the epilogue of the current one, which then stages its rows in the other stage alone (epilogue256t<..., COMPACT>): the
+// prologue of a tile (argument loads, first DMA round trip, 32-64 KiB of LDS fill: ~5 us with the matrix pipe idle) runs
+// under the previous tile's stores.  `stagger` then carries the size of the virtual grid.
+template <typename T, int EPI, int NP = 0, bool QK8 = false, bool WALK = false>   // QK8: GemmParams::out_qk8 (EPI_BIAS, split operands only)
 __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int PN, int patches_n, int total_patches, int PM, int stagger) {
+  static_assert(!WALK || NP != 0, "the walking form exists for split operands (tile-independent per-lane DMA offsets)");
   typedef typename Elem<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[131072];
 
@@ -1068,18 +1082,25 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   const int c16 = lane & 15, q4 = lane >> 4;
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_m = (p.M + 255) >> 8;
-  int tm, tn;
-  {
+  auto map_tile = [&](int b, int& tm_, int& tn_) -> bool {
     const int P = PM * PN;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = b & 7, j = b >> 3;
     const int gp = (j / P) * 8 + xcd, local = j % P;
-    if (gp >= total_patches) return;
+    if (gp >= total_patches) return false;
     const int pm = gp / patches_n, pn = gp - pm * patches_n;
-    tm = pm * PM + local / PN;
-    tn = pn * PN + local % PN;
-    if (tm >= tiles_m) return;
+    tm_ = pm * PM + local / PN;
+    tn_ = pn * PN + local % PN;
+    return tm_ < tiles_m;
+  };
+  int tm = 0, tn = 0;
+  int vb = blockIdx.x;
+  if constexpr (WALK) {
+    while (vb < stagger && !map_tile(vb, tm, tn)) vb += gridDim.x;
+    if (vb >= stagger) return;   // whole workgroup, before any barrier
+  } else {
+    if (!map_tile(vb, tm, tn)) return;
   }
-  if (stagger > 1 && blockIdx.x < 256) {
+  if (!WALK && stagger > 1 && blockIdx.x < 256) {
     // De-phase the first round: workgroup slot k of an XCD starts k/stagger of a tile later, and the
     // dispatcher keeps the CUs de-phased afterwards.  Otherwise every CU reaches its epilogue at the
     // same moment and the residual read-modify-write (67 + 67 MB per round) is an HBM burst with no
@@ -1115,14 +1136,19 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   // the descriptors must be PROVABLY wave-uniform, or hipcc wraps every buffer_load ... lds of the K loop in a
   // waterfall loop (v_readfirstlane x4, compare, s_and_saveexec): it lost the proof when the folding epilogue was
   // added and the residual GEMMs ran 15 % slower with an unchanged K loop in source
-  const T* baseA = uniform_ptr((const T*)p.A + (long)tm * 256 * p.lda);
-  const T* baseW = uniform_ptr((const T*)p.W + (long)tn * 256 * ldw);
-  // split operands: num_records = the bytes from this tile's first row to the end of A (out-of-range rows read as zero)
-  const long bytesA = ((long)p.M - (long)tm * 256) * p.lda * 2;
-  const int recA = NP == 0 ? 0x7FFFFFF0 : (int)(bytesA < 0x7FFFFFF0L ? bytesA : 0x7FFFFFF0L);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, __builtin_amdgcn_readfirstlane(recA), 0x00020000);
+  auto desc_a = [&](int tm_) {
+    const T* baseA = uniform_ptr((const T*)p.A + (long)tm_ * 256 * p.lda);
+    // split operands: num_records = the bytes from this tile's first row to the end of A (out-of-range rows read as zero)
+    const long bytesA = ((long)p.M - (long)tm_ * 256) * p.lda * 2;
+    const int recA = NP == 0 ? 0x7FFFFFF0 : (int)(bytesA < 0x7FFFFFF0L ? bytesA : 0x7FFFFFF0L);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, __builtin_amdgcn_readfirstlane(recA), 0x00020000);
+  };
+  auto desc_w = [&](int tn_) {
+    const T* baseW = uniform_ptr((const T*)p.W + (long)tn_ * 256 * ldw);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t rsA = desc_a(tm), rsW = desc_w(tn);
   const int subA = 64 * (int)p.lda * 2, subW = 32 * ldw * 2;   // bytes from a DMA piece of half 0 to the same piece of half 1
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)baseW, 0, 0x7FFFFFF0, 0x00020000);
   int offM[2][2], offN[2][2];   // [ks][tile parity]
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -1132,13 +1158,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
       offN[ks][par] = 32768 + tile_off_id(wc * 64 + par * 16 + c16, 4 * ks + q4);
     }
 
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  f32x4 acc[8][4];   // zeroed at the head of every tile (below)
   // LayerNorm folding: this lane's (rstd, -mean*rstd) pairs, requested now so that they are there at the epilogue
   f32x2 ab_pre[8];
   const bool fold_pre = NP == 0 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.row_ab != nullptr;
@@ -1158,10 +1178,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   (void)sc_pack;
 #define DMA(rs, src, dst, st, so) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (st) * 65536 + dst), 16, src, so, 0, 0);
-#define GA(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd) + (NP != 0 ? (sub) * subA : 0); \
-    DMA(rsA, srcA[NP != 0 ? 0 : (sub)][0], dstA[sub][0], st, so) DMA(rsA, srcA[NP != 0 ? 0 : (sub)][1], dstA[sub][1], st, so) }
-#define GW(sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd) + (NP != 0 ? (sub) * subW : 0); \
-    DMA(rsW, srcW[NP != 0 ? 0 : (sub)][0], dstW[sub][0], st, so) DMA(rsW, srcW[NP != 0 ? 0 : (sub)][1], dstW[sub][1], st, so) }
+#define GAx(rs, sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd) + (NP != 0 ? (sub) * subA : 0); \
+    DMA(rs, srcA[NP != 0 ? 0 : (sub)][0], dstA[sub][0], st, so) DMA(rs, srcA[NP != 0 ? 0 : (sub)][1], dstA[sub][1], st, so) }
+#define GWx(rs, sub, st, kt) { int kd; const int so = vtile_off<NP>(kt, p.K, kd) + (NP != 0 ? (sub) * subW : 0); \
+    DMA(rs, srcW[NP != 0 ? 0 : (sub)][0], dstW[sub][0], st, so) DMA(rs, srcW[NP != 0 ? 0 : (sub)][1], dstW[sub][1], st, so) }
+#define GA(sub, st, kt) GAx(rsA, sub, st, kt)
+#define GW(sub, st, kt) GWx(rsW, sub, st, kt)
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define BAR __builtin_amdgcn_s_barrier();
@@ -1246,8 +1268,25 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   // prologue: B0, A0, B1, A1 of tile 0 and B0 of tile 1; B0(0) in registers, A0(0) confirmed
   GW(0, 0, 0) GA(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
   if (nk > 1) GW(0, 1, 1)
+  bool first_tile = true;
+#pragma unroll 1
+  for (;;) {   // (one trip unless WALK)
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   FragPair<T, NP != 0> fm[4], fnX[2], fnY[2];
-  if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
+  if (!WALK || first_tile) {
+    if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
+  } else {
+    // a later tile of a walk: its first K tile was issued before the previous epilogue's stores, B0 of its second K tile
+    // after them.  Loads return in order among loads: once at most two operations are outstanding, every load older than
+    // the two youngest has landed (an outstanding older load would make three).  Stores still in flight only make the
+    // counted waits of the K loop stricter.
+    if (nk > 1) WAIT_VM(2); else WAIT_VM(0);
+  }
   BAR
   LD_N(fnX, smem, 0)
 #ifndef X_NO_STAGGER
@@ -1279,9 +1318,34 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #ifndef X_NO_STAGGER
   if (wr == 0) BAR   // balance the barrier count of the two groups
 #endif
+  if constexpr (!WALK) {
+    epilogue256t<T, EPI, NP != 0, QK8>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
+    break;
+  } else {
+    // every wave is past its last MFMA cluster, and stage 0 was last read one K tile ago (nk is even: the last K tile lives
+    // in stage 1): the next tile's first K tile goes there now, under this tile's epilogue, which stages in stage 1 alone
+    int tm2 = 0, tn2 = 0, vb2 = vb + (int)gridDim.x;
+    while (vb2 < stagger && !map_tile(vb2, tm2, tn2)) vb2 += gridDim.x;
+    const bool more_tiles = vb2 < stagger;
+    const __amdgpu_buffer_rsrc_t rsA2 = desc_a(more_tiles ? tm2 : tm), rsW2 = desc_w(more_tiles ? tn2 : tn);
+    if (more_tiles) { GWx(rsW2, 0, 0, 0) GAx(rsA2, 0, 0, 0) GWx(rsW2, 1, 0, 0) GAx(rsA2, 1, 0, 0) }
+    epilogue256t<T, EPI, true, QK8, 4, true>(p, acc, smem + 65536, tm, tn, wave, lane, nullptr);
+    if (!more_tiles) break;
+    __syncthreads();   // every wave is done with its staging rows: stage 1 may take B0 of the next tile's second K tile
+    if (nk > 1) GWx(rsW2, 0, 1, 1)
+    tm = tm2;
+    tn = tn2;
+    vb = vb2;
+    rsA = rsA2;
+    rsW = rsW2;
+    first_tile = false;
+  }
+  }
 #undef DMA
 #undef GA
 #undef GW
+#undef GAx
+#undef GWx
 #undef WAIT_VM
 #undef LGKM0
 #undef BAR
@@ -1293,7 +1357,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef MM8
 #undef QUADX
 #undef KTILE
-  epilogue256t<T, EPI, NP != 0, QK8>(p, acc, smem, tm, tn, wave, lane, fold_pre ? ab_pre : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1572,7 +1635,19 @@ static void patch_shape(int tiles_n, int& PMx, int& PN) {
   }
 }
 
-template <int NP>
+// WALK: one workgroup per CU walks the tiles of the same virtual grid (gemm16_256x_kernel<..., WALK>)
+static int walk_grid() {
+  static int g = 0;
+  if (g == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;
+    g = cus / 8 * 8;   // a multiple of the 8 XCDs: workgroup w and its later tiles w + g, w + 2g, ... stay on XCD w % 8
+  }
+  return g;
+}
+
+template <int NP, bool WALK = false>
 static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
   const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;
   int PN, PMx;
@@ -1580,16 +1655,18 @@ static void launch_split(int epi, const GemmParams& p, hipStream_t s) {
   const int patches_n = tiles_n / PN;
   const int pm_x = (tiles_m + PMx - 1) / PMx;
   const int total_x = patches_n * pm_x;
-  dim3 gx(((total_x + 7) / 8) * 8 * PMx * PN), b(512);
+  const int vgrid = ((total_x + 7) / 8) * 8 * PMx * PN;
+  dim3 gx(WALK ? (vgrid < walk_grid() ? vgrid : walk_grid()) : vgrid), b(512);
+  const int last = WALK ? vgrid : 1;   // WALK: the size of the virtual grid; otherwise the start stagger (off)
   switch (epi) {
     case EPI_BIAS:
-      if (p.out_qk8) hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP, true>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1);
-      else hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1);
+      if (p.out_qk8) hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP, true, WALK>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, last);
+      else hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS, NP, false, WALK>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, last);
       break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_RESID, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
-    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_ACT_F32, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
-    case EPI_PATCH: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_PATCH, NP>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, 1); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP, false, WALK>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, last); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_BIAS_RESID, NP, false, WALK>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, last); break;
+    case EPI_ACT_F32: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_ACT_F32, NP, false, WALK>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, last); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm16_256x_kernel<f16, EPI_PATCH, NP, false, WALK>), gx, b, 0, s, p, PN, patches_n, total_x, PMx, last); break;
     default: set_launch_error("gemm: no 256-tile kernel for this epilogue");
   }
   if (p.out_qk8 && epi != EPI_BIAS) set_launch_error("gemm: out_qk8 goes with the bias epilogue only");
@@ -1731,10 +1808,13 @@ void launch_gemm256t(int dtype, int epi, const GemmParams& p, hipStream_t s, int
     return;
   }
   if (dtype == AACLIP_F16X2) {
-    if (p.w_exact16) launch_split<3>(epi, p, s);
+    if (overlapped == 16) {   // the walking form of the 8-wave kernel (split operands only)
+      if (p.w_exact16) launch_split<3, true>(epi, p, s);
+      else launch_split<4, true>(epi, p, s);
+    } else if (p.w_exact16) launch_split<3>(epi, p, s);
     else launch_split<4>(epi, p, s);
-  } else if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped);
-  else launch_t<bf16>(epi, p, s, overlapped);
+  } else if (dtype == AACLIP_F16) launch_t<f16>(epi, p, s, overlapped == 16 ? 14 : overlapped);
+  else launch_t<bf16>(epi, p, s, overlapped == 16 ? 14 : overlapped);
 }
 
 }  // namespace aaclip

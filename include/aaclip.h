@@ -239,9 +239,10 @@ int aaclip_profile_begin(unsigned tag_mask, int capacity);
 int aaclip_profile_end(float* ms, int* tags, int max_n);
 
 /* Kernel selection for A/B measurements (tools/bench_gemm.py, tools/bench_attn.py); 0 = automatic (default).
- * bits 0..7   GEMM: 1 = always the 128x128-tile kernel; 80 / 81 = where the automatic choice is a 256-row-tile kernel,
- *             always the 8-wave 256x256 one / the 4-wave 256x128 half-tile one (bit-identical results; 0 picks the
- *             faster).  Measurement library only: 2..5 = 256-tile kernels on
+ * bits 0..7   GEMM: 1 = always the 128x128-tile kernel; 80 / 81 / 82 = where the automatic choice is a 256-row-tile
+ *             kernel, always the 8-wave 256x256 one with one tile per workgroup / the 4-wave 256x128 half-tile one /
+ *             the 8-wave one walking its tiles (split operands; one workgroup per CU) -- bit-identical results; 0
+ *             picks the fastest.  Measurement library only: 2..5 = 256-tile kernels on
  *             32x32x16 MFMAs; 6..60 = the 16x16x32 family (20 = the default kernel, others: lock-step /
  *             in-cluster-read variants, timing ablations and the stamp build); 70 = persistent tiles (gemm256z.hip)
  * bits 8..15  attention: 1 = always the 128-query kernel; measurement library only: 2 = software-pipelined kernel

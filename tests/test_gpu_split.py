@@ -326,14 +326,17 @@ def test_block_long_rows_take_the_e4m3_attention_form(dev, shape):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# the two 256-row-tile GEMM kernels (8 waves, 256 x 256 / 4 waves, 256 x 128, two workgroups per CU) compute the same sums
-# in the same order: every output must be BIT-identical between aaclip_set_gemm_variant(80) and (81)
+# the 256-row-tile GEMM kernels (8 waves, 256 x 256, one tile per workgroup = 80 / 4 waves, 256 x 128, two workgroups per
+# CU = 81 / the 8-wave kernel walking its tiles, one workgroup per CU, the next tile's first K tile fetched under the
+# epilogue = 82, the default for split operands) compute the same sums in the same order: every output must be
+# BIT-identical between aaclip_set_gemm_variant(80), (81) and (82).  Shapes with more than 256 tiles make 82 really walk.
 # ------------------------------------------------------------------------------------------------------------------
 def _variant(lib, v):
     assert lib.aaclip_set_gemm_variant(v) == 0, v
 
 
-@pytest.mark.parametrize("shape", [(4300, 256, 128), (5480, 1024, 1024), (4097, 768, 384), (6000, 512, 2048)])
+@pytest.mark.parametrize("shape", [(4300, 256, 128), (5480, 1024, 1024), (4097, 768, 384), (6000, 512, 2048),
+                                   (40000, 1024, 256), (70001, 256, 384), (33000, 3072, 128)])
 def test_gemm_half_tile_kernel_is_bit_identical_split(dev, shape):
     lib = _lib.load()
     M, N, K = shape
@@ -344,7 +347,7 @@ def test_gemm_half_tile_kernel_is_bit_identical_split(dev, shape):
     x0 = synth.randn("t.h.x", (M, N), 2.0, 4)
     res = {}
     try:
-        for v in (80, 81):
+        for v in (80, 81, 82):
             _variant(lib, v)
             outs = []
             o16 = torch.full((M + 2, 4 * N), 0xAA, dtype=torch.uint8, device=dev)
@@ -361,8 +364,10 @@ def test_gemm_half_tile_kernel_is_bit_identical_split(dev, shape):
             res[v] = outs
     finally:
         _variant(lib, 0)
-    for a, b, what in zip(res[80], res[81], ("bias", "gelu", "resid", "leaky")):
+    for a, b, c, what in zip(res[80], res[81], res[82], ("bias", "gelu", "resid", "leaky")):
         assert torch.equal(a, b), f"{what} {shape}: the half-tile kernel differs from the 8-wave kernel"
+        assert torch.equal(a, c), f"{what} {shape}: the walking kernel differs from the 8-wave kernel"
+    assert bool((res[82][3][M:] == 7.5).all()) and bool((res[82][0][M:] == 0xAA).all())     # rows past M untouched
     assert bool((res[81][3][M:] == 7.5).all()) and bool((res[81][0][M:] == 0xAA).all())     # rows past M untouched
     assert_close(res[81][3][:M], O.leaky_relu(A.double() @ W.double().t()), 3e-4, 1e-4, f"half-tile leaky {shape}")
 
@@ -400,11 +405,13 @@ def test_gemm_half_tile_kernel_is_bit_identical_plain(dev, dtype):
         assert_close(res[81][2], ref, 2e-2 if dtype == "bf16" else 4e-3, 1e-2, f"half-tile resid {dtype}")
 
 
+@pytest.mark.parametrize("B", [4, 16])
 @pytest.mark.parametrize("exact", [False, True])
-def test_blocks_half_tile_kernel_is_bit_identical(dev, exact):
-    """Two full-size blocks through aaclip_blocks (B = 4: M = 5480 rows, the 256-row-tile regime) in fp16x2, with the
-    weights as drawn (4 virtual tiles per K pair) and rounded through fp16 (3 tiles; the QKV product writes the attention
-    kernel's e4m3 records in both): the stream after the blocks is bit-identical under both GEMM kernels."""
+def test_blocks_half_tile_kernel_is_bit_identical(dev, exact, B):
+    """Two full-size blocks through aaclip_blocks (B = 4: M = 5480 rows, the 256-row-tile regime; B = 16: 344 to 1376
+    tiles per product, so the walking kernel takes several tiles per workgroup) in fp16x2, with the weights as drawn (4
+    virtual tiles per K pair) and rounded through fp16 (3 tiles; the QKV product writes the attention kernel's e4m3 records
+    in both): the stream after the blocks is bit-identical under all three GEMM kernels."""
     from model.clip import create_model
     lib = _lib.load()
     cfg = synth.ClipCfg()
@@ -414,12 +421,12 @@ def test_blocks_half_tile_kernel_is_bit_identical(dev, exact):
     clip = create_model("ViT-L-14-336", 518, pretrained=None, precision="fp16x2", force_image_size=518)
     clip.load_state_dict(sd, strict=True)
     clip = clip.to(dev).eval()
-    B, L = 4, 1370
+    L = 1370
     x0 = synth.randn("t.hb.x", (B * L, 1024), 1.0, 5).to(dev)
     blocks = list(clip.visual.transformer.resblocks)[:2]
     res = {}
     try:
-        for v in (80, 81):
+        for v in (80, 81, 82):
             _variant(lib, v)
             x = x0.clone()
             with torch.no_grad():
@@ -429,3 +436,4 @@ def test_blocks_half_tile_kernel_is_bit_identical(dev, exact):
         _variant(lib, 0)
     assert torch.isfinite(res[80]).all() and float((res[80] - x0).abs().max()) > 0.1
     assert torch.equal(res[80], res[81])
+    assert torch.equal(res[80], res[82])

@@ -300,20 +300,30 @@ def test_gemm_k_loop_has_no_waterfall_loops(tmp_path):
     # For those a spill is worse than slow: a spilled address comes back through scratch_load + s_waitcnt vmcnt(0),
     # which drains the DMA pipeline once per tile (measured: 1.60 -> 1.35 ms per c_fc launch when the last one went).
     # (the last template flag: the QKV product writing the attention kernel's e4m3 records, GemmParams::out_qk8)
-    for epi, np_, qk8 in [(e, n, 0) for n in (0, 4, 3) for e in range(5)] + [(0, 4, 1), (0, 3, 1)]:
-        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}ELi{np_}ELb{qk8}EEEvNS_10GemmParamsEiiiii:"
+    # (the very last flag: the WALKING form -- one workgroup per CU, the next tile's first K tile fetched under the epilogue
+    # -- which exists for the split instantiations and is their default.  Its descriptors are loop-carried, which is
+    # exactly where hipcc could lose the uniformity proof.  Between the K loop's last barrier and the epilogue's first one it
+    # builds the next tile's descriptors with v_readfirstlane on purpose: that stretch is left out.)
+    cases = [(e, n, 0, 0) for n in (0, 4, 3) for e in range(5)] + [(0, 4, 1, 0), (0, 3, 1, 0)]
+    cases += [(e, n, 0, 1) for n in (4, 3) for e in range(5)] + [(0, 4, 1, 1), (0, 3, 1, 1)]
+    for epi, np_, qk8, walk in cases:
+        sym = f"_ZN6aaclip18gemm16_256x_kernelIDF16_Li{epi}ELi{np_}ELb{qk8}ELb{walk}EEEvNS_10GemmParamsEiiiii:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
         body = lines[start:end]
         first_store = next(i for i, l in enumerate(body) if "global_store" in l or "buffer_store" in l)
         bars = [i for i, l in enumerate(body[:first_store]) if "s_barrier" in l]   # (the epilogue has barriers of its own)
-        loop = [l.split()[0] for l in body[bars[0]:bars[-1]] if l.strip() and not l.strip().startswith((".", ";"))]
+        loop = [l.split()[0] for l in body[bars[0]:bars[-2 if walk else -1]] if l.strip() and not l.strip().startswith((".", ";"))]
         assert loop.count("buffer_load_dwordx4") >= 16, (epi, "K loop not found")
         assert "v_readfirstlane_b32" not in loop and "s_and_saveexec_b64" not in loop, \
-            f"EPI {epi} NP {np_}: waterfall loop around the K-loop DMA (descriptor not provably uniform)"
-        assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi} NP {np_}: spill in the K loop"
+            f"EPI {epi} NP {np_} walk {walk}: waterfall loop around the K-loop DMA (descriptor not provably uniform)"
+        assert not any(op.startswith("scratch_") for op in loop), f"EPI {epi} NP {np_} walk {walk}: spill in the K loop"
+        if walk:   # ... and the prefetch of the next tile must not sit in a waterfall loop either
+            tail = [l.split()[0] for l in body[bars[-2]:bars[-1]] if l.strip() and not l.strip().startswith((".", ";"))]
+            assert tail.count("buffer_load_dwordx4") == 8, (epi, np_, "prefetch of the next tile not found")
+            assert "s_and_saveexec_b64" not in tail, f"EPI {epi} NP {np_}: waterfall loop around the next tile's prefetch"
         checked += 1
-    assert checked == 17
+    assert checked == 29
     # the half-tile kernel (4 waves, 256 x 128): the same two properties for every instantiation the launcher can reach
     for epi, np_, qk8 in [(e, n, 0) for n in (0, 4, 3) for e in range(5)] + [(0, 4, 1), (0, 3, 1)]:
         sym = f"_ZN6aaclip18gemm16_256h_kernelIDF16_Li{epi}ELi{np_}ELb{qk8}EEEvNS_10GemmParamsEiiiii:"
