@@ -470,7 +470,7 @@ def run_rank(args):
             achieved = fc_flop / (fc_avg * 1e-3) / 1e12 if fc_avg > 0 else 0.0
             tname = DTYPE_NAME[args.precision]
             kname = {"fp32": "gemm32_kernel<EPI_BIAS_GELU>",
-                     "fp16x2": "gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP=%d>" % (
+                     "fp16x2": "gemm16_256x_kernel<f16, EPI_BIAS_GELU, NP=%d, WALK>" % (
                          3 if args.clip_weights == "fp16" else 4)}.get(
                              args.precision, f"gemm16_256x_kernel<{tname}, EPI_BIAS_GELU>")
             result.update({
