@@ -122,6 +122,10 @@ int aaclip_set_gemm_variant(int v) {
 int aaclip_debug_gemm_stamps(double* out3, int nwaves) {
 #ifdef AACLIP_MEASURE
   REQUIRE(out3, "debug_gemm_stamps: null pointer");
+  if (nwaves == -2) {   // walking kernel's compact epilogue (-DX_WALK_STAMP): 8 sums, reset on read
+    read_gemm_estamps(out3);
+    return 0;
+  }
   if (nwaves < 0) {   // persistent kernel: 8 values (cycles per tile of 7 segments, tile count)
     read_gemm_zstamps(out3);
     return 0;

@@ -29,6 +29,17 @@ template <typename P> AACLIP_DEV P* uniform_ptr(P* ptr) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
   return (P*)(((unsigned long long)hi << 32) | lo);
 }
+#if defined(AACLIP_MEASURE) && defined(X_WALK_STAMP)   // tools/walk_stamps.py: the compact epilogue in segments (wave 0 of a workgroup)
+__device__ unsigned long long g_estamp[8];
+AACLIP_DEV unsigned long long estamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define ES(...) __VA_ARGS__
+#else
+#define ES(...)
+#endif
 // sum over the 16 lanes of a DPP row (rotations by 8, 4, 2, 1), result in every lane
 AACLIP_DEV float row16_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
@@ -84,8 +95,10 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
     // four passes of 32 rows: convert (GELU) + stage + store one pass, then the next, so that the stores of a
     // pass drain while the VALU works on the following one (all CUs reach this point together and the stores
     // are bandwidth-bound: computing everything first and storing afterwards serialises the two)
+    ES(unsigned long long es_cv = 0, es_st = 0;)
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
+      ES(const unsigned long long es0 = estamp();)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int nl = ni * 16 + 4 * q4;   // local column of this lane's 4 values
@@ -160,6 +173,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           }
         }
       }
+      ES(const unsigned long long es1 = estamp(); es_cv += es1 - es0;)
 #pragma unroll
       for (int it = 4 * pass; it < 4 * pass + 4; ++it) {
         const int m = it * 8 + (lane >> 3), c = lane & 7;
@@ -188,7 +202,9 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
         }
       }
+      ES(es_st += estamp() - es1;)
     }
+    ES(if (COMPACT && wave == 0 && lane == 0) { atomicAdd(&g_estamp[0], es_cv); atomicAdd(&g_estamp[1], es_st); atomicAdd(&g_estamp[2], 1ull); })
   } else {
     // fp32 outputs.  In the accumulator layout the 16 lanes of a quarter-wave hold 16 different rows, i.e. one
     // global instruction would touch 64 cache lines for 1 KiB; staged through LDS (64 rows x 256 B per
@@ -203,6 +219,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
     if (EPI == EPI_BIAS_RESID || (EPI == EPI_ACT_F32 && p.bias)) bv = *(const f32x4*)(p.bias + n0);
 #pragma unroll
     for (int half = 0; half < PARTS; ++half) {
+      ES(const unsigned long long ef0 = estamp();)
       f32x4 extra[PIT];
       long orow[PIT];
 #pragma unroll
@@ -226,6 +243,7 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           const int m = mi * 16 + c16;
           *(f32x4*)(st + m * 256 + (((ni * 4 + q4) ^ (m & 15)) << 4)) = acc[half * PMI + mi][ni];
         }
+      ES(const unsigned long long ef1 = estamp(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long ef2 = estamp();)
 #pragma unroll
       for (int it = 0; it < PIT; ++it) {
         const int m = it * 4 + rr;
@@ -267,9 +285,11 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
           }
         }
       }
+      ES(if (COMPACT && wave == 0 && lane == 0) { atomicAdd(&g_estamp[3], ef1 - ef0); atomicAdd(&g_estamp[4], ef2 - ef1); atomicAdd(&g_estamp[5], estamp() - ef2); atomicAdd(&g_estamp[6], 1ull); })
     }
   }
 }
+#undef ES
 
 #ifdef AACLIP_MEASURE   // lock-step predecessors of the staggered kernels, kept for A/B runs (measurement library)
 template <typename T, int EPI>
@@ -1269,6 +1289,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
   GW(0, 0, 0) GA(0, 0, 0) GW(1, 0, 0) GA(1, 0, 0)
   if (nk > 1) GW(0, 1, 1)
   bool first_tile = true;
+#if defined(AACLIP_MEASURE) && defined(X_WALK_STAMP)   // tools/walk_stamps.py: where a walked tile's time goes, per wave
+  unsigned long long ws_wait = 0, ws_loop = 0, ws_pre = 0, ws_epi = 0, ws_tiles = 0, ws_t0 = stamp(), ws_first = 0;
+#define WS(x) x
+#else
+#define WS(x)
+#endif
 #pragma unroll 1
   for (;;) {   // (one trip unless WALK)
 #pragma unroll
@@ -1278,6 +1304,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   FragPair<T, NP != 0> fm[4], fnX[2], fnY[2];
+  WS(const unsigned long long ws_a = stamp();)
   if (!WALK || first_tile) {
     if (nk > 1) WAIT_VM(6); else WAIT_VM(4);
   } else {
@@ -1288,6 +1315,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     if (nk > 1) WAIT_VM(2); else WAIT_VM(0);
   }
   BAR
+  WS(const unsigned long long ws_b = stamp(); if (first_tile) ws_first = ws_b - ws_t0; else ws_wait += ws_b - ws_a;)
   LD_N(fnX, smem, 0)
 #ifndef X_NO_STAGGER
   if (wr == 1) BAR   // waves 4-7 now run one segment behind waves 0-3
@@ -1327,9 +1355,23 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
     int tm2 = 0, tn2 = 0, vb2 = vb + (int)gridDim.x;
     while (vb2 < stagger && !map_tile(vb2, tm2, tn2)) vb2 += gridDim.x;
     const bool more_tiles = vb2 < stagger;
+    WS(const unsigned long long ws_c = stamp(); ws_loop += ws_c - ws_b;)
     const __amdgpu_buffer_rsrc_t rsA2 = desc_a(more_tiles ? tm2 : tm), rsW2 = desc_w(more_tiles ? tn2 : tn);
     if (more_tiles) { GWx(rsW2, 0, 0, 0) GAx(rsA2, 0, 0, 0) GWx(rsW2, 1, 0, 0) GAx(rsA2, 1, 0, 0) }
+    WS(const unsigned long long ws_d = stamp(); ws_pre += ws_d - ws_c;)
     epilogue256t<T, EPI, true, QK8, 4, true>(p, acc, smem + 65536, tm, tn, wave, lane, nullptr);
+    WS(ws_epi += stamp() - ws_d; ws_tiles += 1;)
+#if defined(AACLIP_MEASURE) && defined(X_WALK_STAMP)
+    if (!more_tiles) {
+      if (lane == 0) {
+        const int w = (int)blockIdx.x * 8 + wave;
+        if (w < 16384) {
+          g_stamp[6 * w + 0] = ws_wait; g_stamp[6 * w + 1] = ws_loop; g_stamp[6 * w + 2] = ws_pre;
+          g_stamp[6 * w + 3] = ws_epi; g_stamp[6 * w + 4] = ws_tiles; g_stamp[6 * w + 5] = ws_first;
+        }
+      }
+    }
+#endif
     if (!more_tiles) break;
     __syncthreads();   // every wave is done with its staging rows: stage 1 may take B0 of the next tile's second K tile
     if (nk > 1) GWx(rsW2, 0, 1, 1)
@@ -1346,6 +1388,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_256x_kernel(GemmParams p, int P
 #undef GW
 #undef GAx
 #undef GWx
+#undef WS
 #undef WAIT_VM
 #undef LGKM0
 #undef BAR
@@ -1781,6 +1824,16 @@ static void launch_t(int epi, const GemmParams& p, hipStream_t s, int overlapped
 }
 
 #ifdef AACLIP_MEASURE
+#ifdef X_WALK_STAMP
+void read_gemm_estamps(double* out8) {   // sums since the last read, then reset
+  unsigned long long host[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_estamp), sizeof(host));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_estamp), zero, sizeof(zero));
+  for (int j = 0; j < 8; ++j) out8[j] = (double)host[j];
+}
+#else
+void read_gemm_estamps(double* out8) { for (int j = 0; j < 8; ++j) out8[j] = 0; }
+#endif
 void read_gemm_stamps(double* out6, int nwaves) {
   static unsigned long long host[6 * 16384];
   (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(host));

@@ -60,6 +60,7 @@ void launch_gemm256(int dtype, int epi, const GemmParams& p, hipStream_t s, int 
 void read_gemm_zstamps(double* out8);   // -DZ_STAMP builds only, zeros otherwise
 bool launch_gemm256z(int dtype, int epi, const GemmParams& p, hipStream_t s);   // persistent tiles; false = not applicable
 void read_gemm_stamps(double* out3, int nwaves);
+void read_gemm_estamps(double* out8);   // -DX_WALK_STAMP builds of the measurement library only, zeros otherwise
 void read_attn_passes(unsigned long long* out4, int reset);
 void read_attn_stamps(unsigned long long* out9, int reset);   // -DATTN_STAMP builds: cycles per tile-loop segment   // attn16x2 tile passes: [0] tile 0, [1] fast, [2] exact redo
 #endif
