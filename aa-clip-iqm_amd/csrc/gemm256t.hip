@@ -174,32 +174,65 @@ AACLIP_DEV void epilogue256t(const GemmParams& p, f32x4 (&acc)[8][4], char* smem
         }
       }
       ES(const unsigned long long es1 = estamp(); es_cv += es1 - es0;)
+      // Read the pass back (all LDS reads first: one wait instead of one per store) and store it.  Addresses: one 64-bit
+      // base per lane for the whole tile (row m_base + lane / 8, this lane's chunk), plus a wave-uniform row offset per
+      // store; the per-lane row test only in tiles that reach past M (a wave-uniform branch).  Before: ~25 instructions
+      // of 64-bit multiplies, compares and exec-mask branches per stored row group, and every ds_read waited for alone.
+      {
+        const int c = lane & 7, r8 = lane >> 3;
+        u32x4 vh[4], vl[4];
 #pragma unroll
-      for (int it = 4 * pass; it < 4 * pass + 4; ++it) {
-        const int m = it * 8 + (lane >> 3), c = lane & 7;
-        const int row = m_base + m;
+        for (int k = 0; k < 4; ++k) {
+          const int m = (4 * pass + k) * 8 + r8;
+          if constexpr (SPLIT) {
+            const char* sp = st + (m & SROWS) * 128 + ((c ^ (m & 7)) << 4);
+            vh[k] = *(const u32x4*)sp;
+            vl[k] = *(const u32x4*)(sp + SPL);
+          } else {
+            vh[k] = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
+          }
+        }
+        char* const hb = (char*)((T*)p.out + (long)(m_base + r8) * p.ldc + n_base + c * 8);   // hi / 16-bit chunk of row r8
+        // second store of a split row: lo tile (split16), e4m3 record (QK8) or e4m3 planes (split8)
+        char* lb = hb;
+        bool second = false;
         if constexpr (SPLIT) {
-          const char* sp = st + (m & SROWS) * 128 + ((c ^ (m & 7)) << 4);
-          const u32x4 vh = *(const u32x4*)sp;
-          const u32x4 vl = *(const u32x4*)(sp + SPL);
-          if (row < p.M) {
-            T* orow = (T*)p.out + (long)row * p.ldc;
-            ST_OUT((u32x4*)(orow + n_base + c * 8), vh);
-            if constexpr (EPI == EPI_BIAS) {
-              if constexpr (QK8) {   // the 128-byte e4m3 record of (row, this wave's head), behind the N fp16 values
-                if (n_base < p.out_qk8) ST_OUT((u32x4*)((char*)orow + 2 * p.N + (n_base >> 6) * 128 + c * 16), vl);
-              } else {
-                ST_OUT((u32x4*)(orow + p.N + n_base + c * 8), vl);
-              }
+          char* const rb = (char*)((T*)p.out + (long)(m_base + r8) * p.ldc);
+          if constexpr (EPI == EPI_BIAS) {
+            if constexpr (QK8) {
+              lb = rb + 2 * p.N + (n_base >> 6) * 128 + c * 16;
+              second = n_base < p.out_qk8;
             } else {
-              // chunk c < 4: bytes [16c, 16c+16) of this wave's 64 lo8 columns; c >= 4: of its hi8 columns
-              char* o8 = (char*)orow + 2 * p.N + (c >> 2) * p.N + n_base + (c & 3) * 16;
-              if (c < 4 || !p.out_no_hi8) ST_OUT((u32x4*)o8, vl);
+              lb = rb + ((long)p.N + n_base + c * 8) * sizeof(T);
+              second = true;
+            }
+          } else {
+            lb = rb + 2 * p.N + (c >> 2) * p.N + n_base + (c & 3) * 16;
+            second = c < 4 || !p.out_no_hi8;
+          }
+        }
+        const long rstride = (long)p.ldc * sizeof(T) * 8;   // bytes between consecutive row groups (wave-uniform)
+        const bool inside = m_base + 128 <= p.M;            // wave-uniform: every row of this wave's band exists
+        if (inside) {   // (two copies of the four stores: the common one has no per-lane row test and no exec-mask branches)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int it = 4 * pass + k;
+            ST_OUT((u32x4*)(hb + it * rstride), vh[k]);
+            if constexpr (SPLIT) {
+              if (second) ST_OUT((u32x4*)(lb + it * rstride), vl[k]);
             }
           }
         } else {
-          const u32x4 v = *(const u32x4*)(st + m * 128 + ((c ^ (m & 7)) << 4));
-          if (row < p.M) ST_OUT((u32x4*)((T*)p.out + (long)row * p.ldc + n_base + c * 8), v);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int it = 4 * pass + k;
+            if (m_base + it * 8 + r8 < p.M) {
+              ST_OUT((u32x4*)(hb + it * rstride), vh[k]);
+              if constexpr (SPLIT) {
+                if (second) ST_OUT((u32x4*)(lb + it * rstride), vl[k]);
+              }
+            }
+          }
         }
       }
       ES(es_st += estamp() - es1;)
